@@ -1,0 +1,116 @@
+/*
+ * eggsim_oracle.h -- CPU restatement of the XPBD particle step of
+ * Clemapfel/egg_fluid_simulation (simulation_handler.lua).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it.  The product
+ * (egg_fluid_simulation_amd/, include/eggsim.h) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors
+ * and no Lua interpreter exists in this pipeline, so this
+ * restatement cannot be checked against the running reference.  It is pinned
+ * instead by (a) an independently written Python transliteration
+ * (oracle/reference_model.py) that must agree bit-for-bit, and (b) the
+ * closed-form known-answer tests in tests/test_oracle.py.
+ *
+ * All citations "L:a-b" are line ranges of /root/reference/simulation_handler.lua,
+ * "M:a-b" of /root/reference/math.lua.
+ */
+#ifndef EGGSIM_ORACLE_H
+#define EGGSIM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct egg_oracle egg_oracle;
+
+/* the ten solver-relevant config keys (L:1152-1249) */
+typedef struct {
+    double damping;
+    double follow_strength;
+    double cohesion_strength;
+    double cohesion_interaction_distance_factor;
+    double collision_strength;
+    double collision_overlap_factor;
+    double min_mass, max_mass;
+    double min_radius, max_radius;
+} egg_oracle_config;
+
+enum { EGG_ORACLE_WHITE = 0, EGG_ORACLE_YOLK = 1 };
+
+/* particle fields readable through egg_oracle_copy_field */
+enum {
+    EGG_ORACLE_X = 0, EGG_ORACLE_Y, EGG_ORACLE_VX, EGG_ORACLE_VY,
+    EGG_ORACLE_PREV_X, EGG_ORACLE_PREV_Y, EGG_ORACLE_RADIUS, EGG_ORACLE_MASS_T,
+    EGG_ORACLE_MASS, EGG_ORACLE_INV_MASS, EGG_ORACLE_CELL_X, EGG_ORACLE_CELL_Y,
+    EGG_ORACLE_BATCH_ID, EGG_ORACLE_LAST_X, EGG_ORACLE_LAST_Y,
+    EGG_ORACLE_N_FIELDS
+};
+
+/* one record per call of _solve_collision (L:1548) */
+typedef struct {
+    int32_t which;       /* white / yolk */
+    int32_t sub_step;    /* 0-based */
+    int32_t pass;        /* 0-based collision pass */
+    int32_t cut;         /* 1 if the budget return (L:1658) fired */
+    int64_t n_visited;   /* n_collided increments (L:1657) */
+    int64_t n_active;    /* pairs whose collision branch ran (L:1641) */
+} egg_oracle_pass_stat;
+
+/* one record per visited pair, in visiting order (only when tracing) */
+typedef struct {
+    int32_t self_i;      /* 0-based particle index */
+    int32_t other_i;
+    int32_t pass_seq;    /* index into the pass-stat array of this step */
+    int32_t active;
+} egg_oracle_pair;
+
+egg_oracle *egg_oracle_create(const egg_oracle_config *white, const egg_oracle_config *yolk);
+void egg_oracle_destroy(egg_oracle *o);
+void egg_oracle_set_config(egg_oracle *o, int which, const egg_oracle_config *cfg);
+
+/* white_n / yolk_n <= 0: derive from the area ratio as `add` does (L:52-58).
+ * Returns the new batch id (1, 2, ...). */
+int64_t egg_oracle_add(egg_oracle *o, double x, double y, double white_radius,
+                       double yolk_radius, int64_t white_n, int64_t yolk_n);
+/* 0 ok, 1 unknown id */
+int egg_oracle_remove(egg_oracle *o, int64_t id);
+int egg_oracle_set_target(egg_oracle *o, int64_t id, double x, double y);
+int egg_oracle_get_target(egg_oracle *o, int64_t id, double *x, double *y);
+int egg_oracle_get_position(egg_oracle *o, int64_t id, double *x, double *y);
+
+/* `update` (L:168-222): returns the number of _step calls made */
+int egg_oracle_update(egg_oracle *o, double delta, double step_delta,
+                      int n_sub_steps, int n_collision_steps);
+/* `_step` (L:1722) directly */
+void egg_oracle_step(egg_oracle *o, double delta, int n_sub_steps, int n_collision_steps);
+
+int64_t egg_oracle_n_particles(const egg_oracle *o, int which);
+int64_t egg_oracle_n_batches(const egg_oracle *o);
+void egg_oracle_copy_field(const egg_oracle *o, int which, int field, double *dst);
+double egg_oracle_elapsed(const egg_oracle *o);
+double egg_oracle_interpolation_alpha(const egg_oracle *o);
+/* env scalars of the last step: [damping, follow_c, collision_c, cohesion_c,
+ * max_n_collisions, cell_radius, min_x, min_y, max_x, max_y, centroid_x,
+ * centroid_y, max_radius, max_velocity, last_centroid_x, last_centroid_y] */
+void egg_oracle_env(const egg_oracle *o, int which, double out[16]);
+
+/* statistics of the most recent _step */
+int egg_oracle_n_pass_stats(const egg_oracle *o);
+void egg_oracle_pass_stats(const egg_oracle *o, egg_oracle_pass_stat *dst);
+/* cumulative over the handler's lifetime */
+int64_t egg_oracle_total_visited(const egg_oracle *o);
+int64_t egg_oracle_total_steps(const egg_oracle *o);
+
+/* pair tracing of the most recent _step (off by default) */
+void egg_oracle_set_trace(egg_oracle *o, int enabled);
+int64_t egg_oracle_n_trace(const egg_oracle *o);
+void egg_oracle_trace(const egg_oracle *o, egg_oracle_pair *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

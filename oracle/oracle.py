@@ -1,0 +1,209 @@
+"""ctypes binding of the CPU oracle (oracle/eggsim_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke().  Nothing under egg_fluid_simulation_amd/ imports it.
+Parity unpinned against the running reference (no Lua interpreter exists in this
+pipeline); see eggsim_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libeggsim_oracle.so")
+
+WHITE, YOLK = 0, 1
+FIELDS = ["x", "y", "vx", "vy", "prev_x", "prev_y", "radius", "mass_t", "mass", "inv_mass",
+          "cell_x", "cell_y", "batch_id", "last_x", "last_y"]
+FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
+ENV_KEYS = ["damping", "follow_compliance", "collision_compliance", "cohesion_compliance",
+            "max_n_collisions", "cell_radius", "min_x", "min_y", "max_x", "max_y", "centroid_x",
+            "centroid_y", "max_radius", "max_velocity", "last_centroid_x", "last_centroid_y"]
+
+CONFIG_KEYS = ["damping", "follow_strength", "cohesion_strength",
+               "cohesion_interaction_distance_factor", "collision_strength",
+               "collision_overlap_factor", "min_mass", "max_mass", "min_radius", "max_radius"]
+
+# simulation_handler_default_config.lua:10-68 (solver keys only)
+DEFAULT_WHITE = dict(damping=0.1, follow_strength=1 - 0.004, cohesion_strength=1 - 0.2,
+                     cohesion_interaction_distance_factor=2, collision_strength=1 - 0.0025,
+                     collision_overlap_factor=2, min_mass=1, max_mass=1 * 1.8, min_radius=4,
+                     max_radius=4)
+DEFAULT_YOLK = dict(damping=0.1, follow_strength=1 - 0.004, cohesion_strength=1 - 0.002,
+                    cohesion_interaction_distance_factor=3, collision_strength=1 - 0.001,
+                    collision_overlap_factor=2, min_mass=1, max_mass=1 * 1.35, min_radius=4,
+                    max_radius=4)
+
+
+class Config(C.Structure):
+    _fields_ = [(k, C.c_double) for k in CONFIG_KEYS]
+
+
+class PassStat(C.Structure):
+    _fields_ = [("which", C.c_int32), ("sub_step", C.c_int32), ("pass_", C.c_int32),
+                ("cut", C.c_int32), ("n_visited", C.c_int64), ("n_active", C.c_int64)]
+
+
+PAIR_DTYPE = np.dtype([("self_i", np.int32), ("other_i", np.int32), ("pass_seq", np.int32),
+                       ("active", np.int32)])
+
+
+def build(force=False):
+    """Compile the oracle with gcc (Makefile in this directory)."""
+    src = os.path.join(_HERE, "eggsim_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        P = C.c_void_p
+        L.egg_oracle_create.restype = P
+        L.egg_oracle_create.argtypes = [C.POINTER(Config), C.POINTER(Config)]
+        L.egg_oracle_destroy.argtypes = [P]
+        L.egg_oracle_set_config.argtypes = [P, C.c_int, C.POINTER(Config)]
+        L.egg_oracle_add.restype = C.c_int64
+        L.egg_oracle_add.argtypes = [P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64]
+        L.egg_oracle_remove.argtypes = [P, C.c_int64]
+        L.egg_oracle_set_target.argtypes = [P, C.c_int64, C.c_double, C.c_double]
+        L.egg_oracle_get_target.argtypes = [P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.egg_oracle_get_position.argtypes = [P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.egg_oracle_update.argtypes = [P, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.egg_oracle_step.argtypes = [P, C.c_double, C.c_int, C.c_int]
+        L.egg_oracle_n_particles.restype = C.c_int64
+        L.egg_oracle_n_particles.argtypes = [P, C.c_int]
+        L.egg_oracle_n_batches.restype = C.c_int64
+        L.egg_oracle_n_batches.argtypes = [P]
+        L.egg_oracle_copy_field.argtypes = [P, C.c_int, C.c_int, C.c_void_p]
+        L.egg_oracle_elapsed.restype = C.c_double
+        L.egg_oracle_elapsed.argtypes = [P]
+        L.egg_oracle_interpolation_alpha.restype = C.c_double
+        L.egg_oracle_interpolation_alpha.argtypes = [P]
+        L.egg_oracle_env.argtypes = [P, C.c_int, C.POINTER(C.c_double)]
+        L.egg_oracle_n_pass_stats.argtypes = [P]
+        L.egg_oracle_pass_stats.argtypes = [P, C.POINTER(PassStat)]
+        L.egg_oracle_total_visited.restype = C.c_int64
+        L.egg_oracle_total_visited.argtypes = [P]
+        L.egg_oracle_total_steps.restype = C.c_int64
+        L.egg_oracle_total_steps.argtypes = [P]
+        L.egg_oracle_set_trace.argtypes = [P, C.c_int]
+        L.egg_oracle_n_trace.restype = C.c_int64
+        L.egg_oracle_n_trace.argtypes = [P]
+        L.egg_oracle_trace.argtypes = [P, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _cfg(d):
+    c = Config()
+    for k in CONFIG_KEYS:
+        setattr(c, k, float(d[k]))
+    return c
+
+
+class Oracle:
+    """Sequential CPU restatement of SimulationHandler (solver part)."""
+
+    def __init__(self, white=None, yolk=None):
+        self._L = lib()
+        w = dict(DEFAULT_WHITE if white is None else white)
+        y = dict((DEFAULT_YOLK if white is None else w) if yolk is None else yolk)
+        self._h = self._L.egg_oracle_create(C.byref(_cfg(w)), C.byref(_cfg(y)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.egg_oracle_destroy(self._h)
+            self._h = None
+
+    def set_config(self, which, cfg):
+        self._L.egg_oracle_set_config(self._h, which, C.byref(_cfg(cfg)))
+
+    def add(self, x, y, white_radius=50.0, yolk_radius=15.0, white_n=0, yolk_n=0):
+        return self._L.egg_oracle_add(self._h, x, y, white_radius, yolk_radius, white_n, yolk_n)
+
+    def remove(self, batch_id):
+        return self._L.egg_oracle_remove(self._h, batch_id)
+
+    def set_target_position(self, batch_id, x, y):
+        return self._L.egg_oracle_set_target(self._h, batch_id, x, y)
+
+    def get_target_position(self, batch_id):
+        x, y = C.c_double(), C.c_double()
+        if self._L.egg_oracle_get_target(self._h, batch_id, C.byref(x), C.byref(y)):
+            raise KeyError(batch_id)
+        return x.value, y.value
+
+    def get_position(self, batch_id):
+        x, y = C.c_double(), C.c_double()
+        if self._L.egg_oracle_get_position(self._h, batch_id, C.byref(x), C.byref(y)):
+            raise KeyError(batch_id)
+        return x.value, y.value
+
+    def update(self, delta, step_delta=1 / 60, n_substeps=2, n_collision_steps=3):
+        return self._L.egg_oracle_update(self._h, delta, step_delta, n_substeps, n_collision_steps)
+
+    def step(self, delta=1 / 60, n_substeps=2, n_collision_steps=3):
+        self._L.egg_oracle_step(self._h, delta, n_substeps, n_collision_steps)
+
+    def n_particles(self, which):
+        return self._L.egg_oracle_n_particles(self._h, which)
+
+    def n_batches(self):
+        return self._L.egg_oracle_n_batches(self._h)
+
+    def field(self, which, name):
+        out = np.empty(self.n_particles(which), dtype=np.float64)
+        self._L.egg_oracle_copy_field(self._h, which, FIELD_ID[name], out.ctypes.data)
+        return out
+
+    def positions(self, which):
+        return self.field(which, "x"), self.field(which, "y")
+
+    @property
+    def elapsed(self):
+        return self._L.egg_oracle_elapsed(self._h)
+
+    @property
+    def interpolation_alpha(self):
+        return self._L.egg_oracle_interpolation_alpha(self._h)
+
+    def env(self, which):
+        buf = (C.c_double * 16)()
+        self._L.egg_oracle_env(self._h, which, buf)
+        return dict(zip(ENV_KEYS, list(buf)))
+
+    def pass_stats(self):
+        n = self._L.egg_oracle_n_pass_stats(self._h)
+        arr = (PassStat * n)()
+        self._L.egg_oracle_pass_stats(self._h, arr)
+        return [dict(which=s.which, sub_step=s.sub_step, pass_=s.pass_, cut=s.cut,
+                     n_visited=s.n_visited, n_active=s.n_active) for s in arr]
+
+    @property
+    def total_visited(self):
+        return self._L.egg_oracle_total_visited(self._h)
+
+    @property
+    def total_steps(self):
+        return self._L.egg_oracle_total_steps(self._h)
+
+    def set_trace(self, on):
+        self._L.egg_oracle_set_trace(self._h, int(bool(on)))
+
+    def trace(self):
+        n = self._L.egg_oracle_n_trace(self._h)
+        out = np.empty(n, dtype=PAIR_DTYPE)
+        if n:
+            self._L.egg_oracle_trace(self._h, out.ctypes.data)
+        return out

@@ -1,0 +1,104 @@
+"""ctypes binding of libeggsim.so (include/eggsim.h).
+
+This is the Python twin of the LuaJIT `ffi.cdef` block in
+lua/egg_fluid_simulation/simulation_handler.lua: every call the Lua wrapper makes
+goes through the same C entry point here.  There is no fallback: if the shared
+library is missing or no HIP device is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# EGGSIM_LIB lets a developer load a diagnostic build (e.g. libeggsim_prof.so); default is the product library
+LIB_PATH = os.environ.get("EGGSIM_LIB") or os.path.join(_HERE, "libeggsim.so")
+
+EGG_OK = 0
+EGG_WARN_UNKNOWN_ID = 1
+EGG_WARN_FEW_PARTICLES = 2
+EGG_ERR_UNKNOWN_ID = -1
+EGG_ERR_INVALID_ARGUMENT = -2
+EGG_ERR_NO_DEVICE = -3
+EGG_ERR_DEVICE = -4
+EGG_ERR_UNSUPPORTED = -5
+EGG_ERR_INTERNAL = -6
+
+WHITE, YOLK = 0, 1
+
+FIELDS = ["x", "y", "vx", "vy", "last_x", "last_y", "radius", "inv_mass", "mass_t", "batch_id"]
+FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
+
+OPT_CLAIM_MARGIN_CELLS = 0
+OPT_TILE_TARGET_PARTICLES = 1
+OPT_TIMING = 2
+OPT_FORCE_SINGLE_TILE = 3
+
+CONFIG_FIELDS = ["damping", "follow_strength", "cohesion_strength",
+                 "cohesion_interaction_distance_factor", "collision_strength",
+                 "collision_overlap_factor", "min_mass", "max_mass", "min_radius", "max_radius",
+                 "max_collision_fraction", "mass_distribution_variance", "eps"]
+
+
+class EggConfig(C.Structure):
+    _fields_ = [(k, C.c_double) for k in CONFIG_FIELDS]
+
+
+class EggStats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("pair_solves", C.c_int64), ("follow_solves", C.c_int64),
+                ("kernel_launches", C.c_int64), ("retiles", C.c_int64), ("redo_steps", C.c_int64),
+                ("n_tiles", C.c_int64 * 2), ("max_tile_particles", C.c_int64 * 2),
+                ("last_step_kernel_ms", C.c_double), ("single_tile", C.c_int64 * 2)]
+
+
+# every symbol include/eggsim.h declares, with its signature
+_SIGNATURES = {
+    "egg_default_config": (C.c_int, [C.c_int, C.POINTER(EggConfig)]),
+    "egg_create": (C.c_int, [C.POINTER(EggConfig), C.POINTER(EggConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "egg_destroy": (None, [C.c_void_p]),
+    "egg_last_error": (C.c_char_p, [C.c_void_p]),
+    "egg_set_config": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(EggConfig)]),
+    "egg_get_config": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(EggConfig)]),
+    "egg_add": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                          C.POINTER(C.c_int64)]),
+    "egg_add_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                               C.c_int64, C.c_int64, C.c_void_p]),
+    "egg_remove": (C.c_int, [C.c_void_p, C.c_int64]),
+    "egg_set_target": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double]),
+    "egg_set_targets_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egg_get_target": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "egg_update": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "egg_step": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
+    "egg_synchronize": (C.c_int, [C.c_void_p]),
+    "egg_get_position": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "egg_get_positions_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egg_get_n_particles": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "egg_list_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
+    "egg_get_elapsed": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "egg_download_particles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "egg_get_stats": (C.c_int, [C.c_void_p, C.POINTER(EggStats)]),
+    "egg_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+}
+
+EXPORTED_SYMBOLS = sorted(_SIGNATURES)
+
+_lib = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libeggsim.so.  Raises LibraryMissing (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LibraryMissing(
+                "libeggsim.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C egg_fluid_simulation_amd/csrc` (needs hipcc; the solver has no CPU path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

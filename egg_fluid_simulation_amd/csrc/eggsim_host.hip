@@ -1,0 +1,1227 @@
+// eggsim_host.hip -- host side of libeggsim.so: handle state, particle creation,
+// tiling, launch orchestration and the C ABI of include/eggsim.h.
+//
+// The reference keeps everything in Lua tables and runs `_step` on the host
+// (simulation_handler.lua, "L:").  Here the particle arrays live in HBM as SoA
+// (double buffered: the inactive buffer is the reference's last_update_x/y,
+// L:1795-1818), the host keeps only batch bookkeeping, and a step is one
+// kernel launch per particle type and tile size class.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/eggsim.h"
+#include "eggsim_device.h"
+
+extern "C" __global__ void egg_step_kernel(EggStepArgs A);
+extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
+                                                   int, double, int32_t *);
+extern "C" __global__ void egg_rederive_kernel(const double *, double *, double *, int, int, double, double, int,
+                                                double, double);
+extern "C" __global__ void egg_centroid_kernel(const double *, const double *, const double *, const double *,
+                                                const int32_t *, const int32_t *, const int32_t *, const int32_t *,
+                                                int, double *, double *);
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr size_t kLdsLimit = 160 * 1024;
+constexpr int kMaxTileParticles = 32000;  // 15-bit local indices in the kernel's pair sequences
+constexpr int kMaxListEntries = 60000;    // 16-bit round stamps in the DAG executor
+
+std::string g_create_error;
+
+template <typename T>
+struct DevBuf {  // growable device array
+    T *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    hipError_t reserve(size_t n, bool keep, hipStream_t s) {
+        if (n <= cap) return hipSuccess;
+        size_t ncap = std::max<size_t>(n, cap ? cap * 2 : 1024);
+        T *q = nullptr;
+        hipError_t e = hipMalloc((void **)&q, ncap * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                (void)hipFree(q);
+                return e;
+            }
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = ncap;
+        return hipSuccess;
+    }
+};
+
+struct Batch {
+    int64_t id = 0;
+    bool alive = false;
+    double target_x = 0, target_y = 0;
+    double white_radius = 0, yolk_radius = 0;
+    int64_t n[2] = {0, 0};
+};
+
+struct Atom {
+    int32_t batch = 0;  // index into Handle::batches
+    int32_t offset = 0, count = 0;
+};
+
+struct Box {
+    int32_t lo_x, lo_y, hi_x, hi_y;
+};
+
+struct LaunchClass {  // tiles of similar size share a launch (uniform LDS geometry)
+    int first_tile = 0, n_tiles = 0;
+    int nmax = 0, amax = 0, ht = 0, lcap = 0;
+    size_t lds = 0;
+};
+
+struct System {  // one particle type
+    egg_config cfg{};
+    int64_t n = 0;
+    int cur = 0;
+    DevBuf<double> x[2], y[2], vx[2], vy[2], inv_mass, radius, mass_t;
+    // atoms (host + device mirrors)
+    std::vector<Atom> atoms;
+    DevBuf<int32_t> d_atom_offset, d_atom_count, d_atom_batch, d_atom_claim, d_atom_aabb;
+    DevBuf<double> d_atom_tx, d_atom_ty, d_atom_fd;
+    std::vector<Box> aabb;  // host copy of the atoms' occupied cells
+    bool aabb_valid = false;
+    bool aabb_on_device = false;  // d_atom_aabb holds the cells of the CURRENT positions (written by the last step)
+    bool atoms_dirty = true, targets_dirty = true, tiling_dirty = true;
+    // tiles
+    std::vector<int32_t> tile_atom_begin, tile_atoms;
+    DevBuf<int32_t> d_tile_atom_begin, d_tile_atoms;
+    std::vector<LaunchClass> classes;
+    int margin = 2;
+    int single_tile = 0;  // exact-budget mode: everything in one tile
+    int uncut_streak = 0;
+    double list_factor = 10.0;  // visit-list capacity per particle, grows on overflow
+    size_t list_min = 0;
+    // environment of the previous step (L:1731-1744)
+    bool has_env = false;
+    double env_min_mass = 0, env_max_mass = 0, env_min_radius = 0, env_max_radius = 0;
+    double tiled_cell_size = 0;
+    EggStatus *d_status = nullptr;
+    EggStatus *h_status = nullptr;  // pinned
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+}  // namespace
+
+struct egg_handle {
+    int device = 0;
+    System sys[2];
+    std::vector<Batch> batches;  // index = id - 1 (ids are never reused, L:999-1000)
+    int64_t n_alive = 0;
+    double elapsed = 0, interpolation_alpha = 0;
+    egg_stats stats{};
+    std::string error;
+    int opt_margin = 2;
+    int opt_tile_target = 0;
+    int opt_timing = 0;
+    int opt_force_single = 0;
+    hipDeviceProp_t prop{};
+};
+
+namespace {
+
+int fail(egg_handle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h)
+        h->error = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                               \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(h, EGG_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                        __FILE__, __LINE__);                                                           \
+    } while (0)
+
+double clampd(double x, double lo, double hi) {  // math.lua:16-26
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+double mixd(double lo, double hi, double t) { return lo * (1 - t) + hi * t; }  // math.lua:33-35
+
+Batch *find_batch(egg_handle *h, int64_t id) {
+    if (id < 1 || id > (int64_t)h->batches.size()) return nullptr;
+    Batch *b = &h->batches[(size_t)id - 1];
+    return b->alive ? b : nullptr;
+}
+const Batch *find_batch(const egg_handle *h, int64_t id) { return find_batch(const_cast<egg_handle *>(h), id); }
+
+// ---------------------------------------------------------------- particles
+
+// the per-particle template of a batch: offsets from the centre, mass factor, mass, radius
+// (fibonacci_spiral L:907-918, get_mass L:921-938, add_particle L:941-997)
+struct ParticleTemplate {
+    std::vector<double> dx, dy, t, inv_mass, radius;
+};
+
+void make_template(const egg_config &cfg, double batch_radius, int64_t n_particles, ParticleTemplate &out) {
+    out.dx.resize((size_t)n_particles);
+    out.dy.resize((size_t)n_particles);
+    out.t.resize((size_t)n_particles);
+    out.inv_mass.resize((size_t)n_particles);
+    out.radius.resize((size_t)n_particles);
+    const double n = (double)n_particles;
+    const double golden_ratio = (1 + std::sqrt(5.0)) / 2;
+    const double golden_angle = 2 * kPi / (golden_ratio * golden_ratio);
+    const double variance = cfg.mass_distribution_variance;
+    auto butterworth = [variance](double t) {
+        double u = variance * (t - 0.5);
+        double u2 = u * u;
+        return 1 / (1 + u2 * u2);
+    };
+    for (int64_t k = 1; k <= n_particles; ++k) {
+        const double i = (double)k;
+        double r = std::sqrt((i - 1) / n);
+        double theta = i * golden_angle;
+        out.dx[(size_t)k - 1] = r * batch_radius * std::cos(theta);
+        out.dy[(size_t)k - 1] = r * batch_radius * std::sin(theta);
+        double left = (i - 0.5) / n;
+        double right = (i + 0.5) / n;
+        double center = 0.5 * (left + right);
+        double half_width = 0.5 * (right - left);
+        double t1 = center - half_width / std::sqrt(3.0);
+        double t2 = center + half_width / std::sqrt(3.0);
+        double t = 0.5 * (butterworth(t1) + butterworth(t2));
+        out.t[(size_t)k - 1] = t;
+        double mass = mixd(cfg.min_mass, cfg.max_mass, t);
+        out.inv_mass[(size_t)k - 1] = 1 / mass;
+        out.radius[(size_t)k - 1] = mixd(cfg.min_radius, cfg.max_radius, t);
+    }
+}
+
+int reserve_particles(egg_handle *h, System &s, int64_t need) {
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(h, s.x[b].reserve((size_t)need, true, s.stream));
+        HIP_TRY(h, s.y[b].reserve((size_t)need, true, s.stream));
+        HIP_TRY(h, s.vx[b].reserve((size_t)need, true, s.stream));
+        HIP_TRY(h, s.vy[b].reserve((size_t)need, true, s.stream));
+    }
+    HIP_TRY(h, s.inv_mass.reserve((size_t)need, true, s.stream));
+    HIP_TRY(h, s.radius.reserve((size_t)need, true, s.stream));
+    HIP_TRY(h, s.mass_t.reserve((size_t)need, true, s.stream));
+    return EGG_OK;
+}
+
+int append_particles(egg_handle *h, System &s, const ParticleTemplate &tp, int64_t n_batches, const double *cx,
+                     const double *cy) {
+    const size_t per = tp.dx.size();
+    const size_t total = per * (size_t)n_batches;
+    int rc = reserve_particles(h, s, s.n + (int64_t)total);
+    if (rc != EGG_OK) return rc;
+    std::vector<double> buf(total);
+    auto upload = [&](double *dst) -> hipError_t {
+        return hipMemcpy(dst + s.n, buf.data(), total * sizeof(double), hipMemcpyHostToDevice);
+    };
+    for (int64_t b = 0; b < n_batches; ++b)
+        for (size_t k = 0; k < per; ++k) buf[(size_t)b * per + k] = cx[b] + tp.dx[k];
+    HIP_TRY(h, upload(s.x[0].p));
+    HIP_TRY(h, upload(s.x[1].p));
+    for (int64_t b = 0; b < n_batches; ++b)
+        for (size_t k = 0; k < per; ++k) buf[(size_t)b * per + k] = cy[b] + tp.dy[k];
+    HIP_TRY(h, upload(s.y[0].p));
+    HIP_TRY(h, upload(s.y[1].p));
+    std::fill(buf.begin(), buf.end(), 0.0);
+    HIP_TRY(h, upload(s.vx[0].p));
+    HIP_TRY(h, upload(s.vx[1].p));
+    HIP_TRY(h, upload(s.vy[0].p));
+    HIP_TRY(h, upload(s.vy[1].p));
+    for (int64_t b = 0; b < n_batches; ++b) std::copy(tp.inv_mass.begin(), tp.inv_mass.end(), buf.begin() + b * per);
+    HIP_TRY(h, upload(s.inv_mass.p));
+    for (int64_t b = 0; b < n_batches; ++b) std::copy(tp.radius.begin(), tp.radius.end(), buf.begin() + b * per);
+    HIP_TRY(h, upload(s.radius.p));
+    for (int64_t b = 0; b < n_batches; ++b) std::copy(tp.t.begin(), tp.t.end(), buf.begin() + b * per);
+    HIP_TRY(h, upload(s.mass_t.p));
+    s.n += (int64_t)total;
+    s.atoms_dirty = s.targets_dirty = s.tiling_dirty = true;
+    s.aabb_valid = s.aabb_on_device = false;
+    return EGG_OK;
+}
+
+// ------------------------------------------------------------------- atoms
+
+int upload_atoms(egg_handle *h, int which) {
+    System &s = h->sys[which];
+    if (s.atoms_dirty) {
+        s.atoms.clear();
+        int64_t off = 0;
+        for (size_t b = 0; b < h->batches.size(); ++b) {
+            const Batch &B = h->batches[b];
+            if (!B.alive) continue;
+            Atom a;
+            a.batch = (int32_t)b;
+            a.offset = (int32_t)off;
+            a.count = (int32_t)B.n[which];
+            off += B.n[which];
+            s.atoms.push_back(a);
+        }
+        const size_t na = s.atoms.size();
+        std::vector<int32_t> o(na), c(na), bb(na);
+        for (size_t k = 0; k < na; ++k) {
+            o[k] = s.atoms[k].offset;
+            c[k] = s.atoms[k].count;
+            bb[k] = s.atoms[k].batch;
+        }
+        HIP_TRY(h, s.d_atom_offset.reserve(na + 1, false, s.stream));
+        HIP_TRY(h, s.d_atom_count.reserve(na + 1, false, s.stream));
+        HIP_TRY(h, s.d_atom_batch.reserve(na + 1, false, s.stream));
+        HIP_TRY(h, s.d_atom_claim.reserve(4 * na + 4, false, s.stream));
+        HIP_TRY(h, s.d_atom_aabb.reserve(4 * na + 4, false, s.stream));
+        HIP_TRY(h, s.d_atom_tx.reserve(na + 1, false, s.stream));
+        HIP_TRY(h, s.d_atom_ty.reserve(na + 1, false, s.stream));
+        HIP_TRY(h, s.d_atom_fd.reserve(na + 1, false, s.stream));
+        if (na) {
+            HIP_TRY(h, hipMemcpy(s.d_atom_offset.p, o.data(), na * 4, hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMemcpy(s.d_atom_count.p, c.data(), na * 4, hipMemcpyHostToDevice));
+            HIP_TRY(h, hipMemcpy(s.d_atom_batch.p, bb.data(), na * 4, hipMemcpyHostToDevice));
+        }
+        s.atoms_dirty = false;
+        s.targets_dirty = true;
+        s.tiling_dirty = true;
+        s.aabb_valid = s.aabb_on_device = false;
+    }
+    if (s.targets_dirty) {
+        const size_t na = s.atoms.size();
+        std::vector<double> tx(na), ty(na), fd(na);
+        for (size_t k = 0; k < na; ++k) {
+            const Batch &B = h->batches[(size_t)s.atoms[k].batch];
+            tx[k] = B.target_x;
+            ty[k] = B.target_y;
+            // target_distance = 2 * batch_id_to_radius[batch_id], radius = sqrt(batch radius) (L:1454, L:1790)
+            fd[k] = 2 * std::sqrt(which == EGG_WHITE ? B.white_radius : B.yolk_radius);
+        }
+        if (na) {
+            HIP_TRY(h, hipMemcpyAsync(s.d_atom_tx.p, tx.data(), na * 8, hipMemcpyHostToDevice, s.stream));
+            HIP_TRY(h, hipMemcpyAsync(s.d_atom_ty.p, ty.data(), na * 8, hipMemcpyHostToDevice, s.stream));
+            HIP_TRY(h, hipMemcpyAsync(s.d_atom_fd.p, fd.data(), na * 8, hipMemcpyHostToDevice, s.stream));
+            HIP_TRY(h, hipStreamSynchronize(s.stream));  // the staging vectors die here
+        }
+        s.targets_dirty = false;
+    }
+    return EGG_OK;
+}
+
+double cell_size_of(const egg_config &c) {  // L:1756-1760
+    double max_factor = std::max(c.collision_overlap_factor, c.cohesion_interaction_distance_factor);
+    return std::max(1.0, c.max_radius * max_factor);
+}
+
+// ------------------------------------------------------------------ tiling
+
+int fetch_end_aabb(egg_handle *h, System &s);
+
+// Groups atoms into tiles.  Atoms whose margin-padded cell boxes come within one cell of
+// each other may interact during the step and must share a tile ("islands": connected
+// components of that relation); independent islands may additionally be packed into one
+// tile to fill a wave.  Each atom's claim box is its padded box: the kernel verifies that
+// no particle leaves it, which proves that particles of different tiles never occupy
+// adjacent cells (claims of different islands are separated by >= 1 empty cell).
+int retile(egg_handle *h, int which) {
+    System &s = h->sys[which];
+    int rc = upload_atoms(h, which);
+    if (rc != EGG_OK) return rc;
+    const size_t na = s.atoms.size();
+    const double cell = cell_size_of(s.cfg);
+    s.tile_atom_begin.assign(1, 0);
+    s.tile_atoms.clear();
+    s.classes.clear();
+    h->stats.n_tiles[which] = 0;
+    h->stats.max_tile_particles[which] = 0;
+    if (na == 0) {
+        s.tiling_dirty = false;
+        s.tiled_cell_size = cell;
+        return EGG_OK;
+    }
+    if (!s.aabb_valid && s.aabb_on_device && s.tiled_cell_size == cell) {
+        rc = fetch_end_aabb(h, s);
+        if (rc != EGG_OK) return rc;
+    }
+    s.tiled_cell_size = cell;
+    if (!s.aabb_valid) {
+        hipLaunchKernelGGL(egg_atom_bounds_kernel, dim3((unsigned)na), dim3(EGG_WAVE), 0, s.stream, s.x[s.cur].p,
+                           s.y[s.cur].p, s.d_atom_offset.p, s.d_atom_count.p, (int)na, cell, s.d_atom_aabb.p);
+        HIP_TRY(h, hipGetLastError());
+        s.aabb.resize(na);
+        HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), s.d_atom_aabb.p, na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipStreamSynchronize(s.stream));
+        s.aabb_valid = true;
+        h->stats.kernel_launches++;
+    }
+    for (const Box &b : s.aabb)
+        if (b.lo_x < -2000000000 || b.hi_x > 2000000000 || b.lo_y < -2000000000 || b.hi_y > 2000000000)
+            return fail(h, EGG_ERR_UNSUPPORTED, "particle coordinates are not finite or exceed +-2e9 cells");
+
+    std::vector<Box> claim(na);
+    std::vector<int> comp(na);
+    const bool single = s.single_tile || h->opt_force_single;
+    if (single) {
+        Box u{std::numeric_limits<int32_t>::max(), std::numeric_limits<int32_t>::max(),
+              std::numeric_limits<int32_t>::min(), std::numeric_limits<int32_t>::min()};
+        for (const Box &b : s.aabb) {
+            u.lo_x = std::min(u.lo_x, b.lo_x);
+            u.lo_y = std::min(u.lo_y, b.lo_y);
+            u.hi_x = std::max(u.hi_x, b.hi_x);
+            u.hi_y = std::max(u.hi_y, b.hi_y);
+        }
+        int64_t ext = std::max<int64_t>((int64_t)u.hi_x - u.lo_x, (int64_t)u.hi_y - u.lo_y);
+        if (ext > 60000) return fail(h, EGG_ERR_UNSUPPORTED, "single-tile extent of %lld cells is too large", (long long)ext);
+        int m = (int)std::min<int64_t>(std::max(s.margin, 64), (60000 - ext) / 2);
+        if (m < 1) m = 1;
+        u = Box{u.lo_x - m, u.lo_y - m, u.hi_x + m, u.hi_y + m};
+        for (size_t k = 0; k < na; ++k) {
+            claim[k] = u;
+            comp[k] = 0;
+        }
+    } else {
+        const int m = s.margin;
+        for (size_t k = 0; k < na; ++k)
+            claim[k] = Box{s.aabb[k].lo_x - m, s.aabb[k].lo_y - m, s.aabb[k].hi_x + m, s.aabb[k].hi_y + m};
+        // union-find over atoms; candidate pairs by a sweep over lo_x
+        std::vector<int> parent(na);
+        std::iota(parent.begin(), parent.end(), 0);
+        auto find = [&](int v) {
+            while (parent[v] != v) {
+                parent[v] = parent[parent[v]];
+                v = parent[v];
+            }
+            return v;
+        };
+        std::vector<int> order(na);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return claim[a].lo_x < claim[b].lo_x; });
+        for (size_t i = 0; i < na; ++i) {
+            const Box &A = claim[order[i]];
+            for (size_t j = i + 1; j < na; ++j) {
+                const Box &B = claim[order[j]];
+                if ((int64_t)B.lo_x > (int64_t)A.hi_x + 1) break;  // a full empty cell column between them
+                if ((int64_t)B.lo_y > (int64_t)A.hi_y + 1 || (int64_t)A.lo_y > (int64_t)B.hi_y + 1) continue;
+                int ra = find(order[i]), rb = find(order[j]);
+                if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+            }
+        }
+        for (size_t k = 0; k < na; ++k) comp[k] = find((int)k);
+    }
+
+    // islands: atoms grouped by component, ascending atom index inside (keeps particle order)
+    std::vector<int> island_of(na, -1);
+    std::vector<std::vector<int32_t>> islands;
+    for (size_t k = 0; k < na; ++k) {
+        int r = comp[k];
+        if (island_of[r] < 0) {
+            island_of[r] = (int)islands.size();
+            islands.emplace_back();
+        }
+        islands[(size_t)island_of[r]].push_back((int32_t)k);
+    }
+    struct TileTmp {
+        std::vector<int32_t> atoms;
+        int64_t particles = 0;
+        Box box{std::numeric_limits<int32_t>::max(), std::numeric_limits<int32_t>::max(),
+                std::numeric_limits<int32_t>::min(), std::numeric_limits<int32_t>::min()};
+    };
+    auto grow = [](Box a, const Box &b) {
+        a.lo_x = std::min(a.lo_x, b.lo_x);
+        a.lo_y = std::min(a.lo_y, b.lo_y);
+        a.hi_x = std::max(a.hi_x, b.hi_x);
+        a.hi_y = std::max(a.hi_y, b.hi_y);
+        return a;
+    };
+    auto extent = [](const Box &b) { return std::max<int64_t>((int64_t)b.hi_x - b.lo_x, (int64_t)b.hi_y - b.lo_y); };
+    std::vector<TileTmp> tiles;
+    const int64_t target = single ? 0 : h->opt_tile_target;
+    for (auto &isl : islands) {
+        int64_t np = 0;
+        TileTmp one;
+        for (int32_t a : isl) {
+            np += s.atoms[(size_t)a].count;
+            one.box = grow(one.box, claim[(size_t)a]);
+        }
+        if (target > 0 && !tiles.empty() && tiles.back().particles + np <= target &&
+            extent(grow(tiles.back().box, one.box)) <= 60000) {
+            // independent islands may share a tile (fills the wave's lanes in the pair executor)
+            TileTmp &tt = tiles.back();
+            tt.atoms.insert(tt.atoms.end(), isl.begin(), isl.end());
+            tt.particles += np;
+            tt.box = grow(tt.box, one.box);
+        } else {
+            one.atoms = isl;
+            one.particles = np;
+            tiles.push_back(std::move(one));
+        }
+    }
+    for (auto &tt : tiles) {
+        std::sort(tt.atoms.begin(), tt.atoms.end());
+        if (tt.particles > kMaxTileParticles)
+            return fail(h, EGG_ERR_UNSUPPORTED,
+                        "%lld particles of one type interact in one island; the LDS tile kernel handles at most %d",
+                        (long long)tt.particles, kMaxTileParticles);
+        int64_t ext_x = 0, ext_y = 0;
+        int32_t lx = std::numeric_limits<int32_t>::max(), ly = lx, hx = std::numeric_limits<int32_t>::min(), hy = hx;
+        for (int32_t a : tt.atoms) {
+            lx = std::min(lx, claim[(size_t)a].lo_x);
+            ly = std::min(ly, claim[(size_t)a].lo_y);
+            hx = std::max(hx, claim[(size_t)a].hi_x);
+            hy = std::max(hy, claim[(size_t)a].hi_y);
+        }
+        ext_x = (int64_t)hx - lx;
+        ext_y = (int64_t)hy - ly;
+        if (ext_x > 65000 || ext_y > 65000)
+            return fail(h, EGG_ERR_UNSUPPORTED, "a tile spans %lld x %lld cells; limit is 65000",
+                        (long long)ext_x, (long long)ext_y);
+    }
+    // big tiles first, and similar sizes adjacent so that they share a launch class
+    std::stable_sort(tiles.begin(), tiles.end(),
+                     [](const TileTmp &a, const TileTmp &b) { return a.particles > b.particles; });
+
+    for (auto &tt : tiles) {
+        s.tile_atoms.insert(s.tile_atoms.end(), tt.atoms.begin(), tt.atoms.end());
+        s.tile_atom_begin.push_back((int32_t)s.tile_atoms.size());
+    }
+    // launch classes: consecutive tiles whose particle count is within 2x
+    size_t t0 = 0;
+    while (t0 < tiles.size()) {
+        size_t t1 = t0;
+        int64_t nmax = tiles[t0].particles;
+        int amax = 0;
+        while (t1 < tiles.size() && tiles[t1].particles * 2 > nmax) {
+            amax = std::max(amax, (int)tiles[t1].atoms.size());
+            ++t1;
+        }
+        LaunchClass lc;
+        lc.first_tile = (int)t0;
+        lc.n_tiles = (int)(t1 - t0);
+        lc.nmax = (int)((nmax + 7) & ~7ll);
+        lc.amax = amax;
+        int ht = 64;
+        while (ht < lc.nmax + lc.nmax / 2) ht *= 2;
+        lc.ht = ht;
+        size_t lcap = std::max<size_t>({(size_t)lc.nmax, (size_t)(s.list_factor * lc.nmax), s.list_min});
+        lcap = std::min<size_t>(lcap, kMaxListEntries);
+        lcap = (lcap + 7) & ~(size_t)7;
+        lc.lcap = (int)lcap;
+        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ht, lc.lcap);
+        if (lc.lds > kLdsLimit)
+            return fail(h, EGG_ERR_UNSUPPORTED,
+                        "a tile of %d particles with %d visit-list entries needs %zu bytes of LDS (limit %zu)",
+                        lc.nmax, lc.lcap, lc.lds, kLdsLimit);
+        s.classes.push_back(lc);
+        t0 = t1;
+    }
+
+    HIP_TRY(h, s.d_tile_atom_begin.reserve(s.tile_atom_begin.size(), false, s.stream));
+    HIP_TRY(h, s.d_tile_atoms.reserve(s.tile_atoms.size() + 1, false, s.stream));
+    HIP_TRY(h, hipMemcpy(s.d_tile_atom_begin.p, s.tile_atom_begin.data(), s.tile_atom_begin.size() * 4,
+                         hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(s.d_tile_atoms.p, s.tile_atoms.data(), s.tile_atoms.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(s.d_atom_claim.p, claim.data(), na * sizeof(Box), hipMemcpyHostToDevice));
+    s.tiling_dirty = false;
+    h->stats.retiles++;
+    h->stats.n_tiles[which] = (int64_t)tiles.size();
+    h->stats.max_tile_particles[which] = tiles.empty() ? 0 : tiles.front().particles;
+    return EGG_OK;
+}
+
+// ------------------------------------------------------------------- step
+
+struct Env {  // scalars of update_environment (L:1726-1774)
+    double sub_delta, damping, follow_c, collision_c, budget, cell;
+};
+
+Env make_env(const egg_config &c, double sub_delta, int64_t n) {
+    Env e;
+    e.sub_delta = sub_delta;
+    auto compliance = [&](double strength) {  // L:1337-1341
+        double alpha = 1 - clampd(strength, 0, 1);
+        return alpha / (sub_delta * sub_delta);
+    };
+    e.damping = 1 - clampd(c.damping, 0, 1);
+    e.follow_c = compliance(c.follow_strength);
+    e.collision_c = compliance(c.collision_strength);
+    double nn = (double)n;
+    e.budget = c.max_collision_fraction * (nn * nn);
+    e.cell = cell_size_of(c);
+    return e;
+}
+
+int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
+    System &s = h->sys[which];
+    if (s.n == 0 || s.classes.empty()) return EGG_OK;
+    EggStatus init;
+    memset(&init, 0, sizeof init);
+    init.min_slack = std::numeric_limits<int32_t>::max();
+    *s.h_status = init;
+    s.aabb_on_device = false;  // the launch overwrites d_atom_aabb
+    HIP_TRY(h, hipMemcpyAsync(s.d_status, s.h_status, sizeof(EggStatus), hipMemcpyHostToDevice, s.stream));
+    if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev0, s.stream));
+    for (const LaunchClass &lc : s.classes) {
+        EggStepArgs A;
+        memset(&A, 0, sizeof A);
+        const int in = s.cur, out = s.cur ^ 1;
+        A.x_in = s.x[in].p;
+        A.y_in = s.y[in].p;
+        A.vx_in = s.vx[in].p;
+        A.vy_in = s.vy[in].p;
+        A.x_out = s.x[out].p;
+        A.y_out = s.y[out].p;
+        A.vx_out = s.vx[out].p;
+        A.vy_out = s.vy[out].p;
+        A.inv_mass = s.inv_mass.p;
+        A.radius = s.radius.p;
+        A.atom_offset = s.d_atom_offset.p;
+        A.atom_count = s.d_atom_count.p;
+        A.atom_batch = s.d_atom_batch.p;
+        A.atom_tx = s.d_atom_tx.p;
+        A.atom_ty = s.d_atom_ty.p;
+        A.atom_fd = s.d_atom_fd.p;
+        A.atom_claim = s.d_atom_claim.p;
+        A.atom_aabb_out = s.d_atom_aabb.p;
+        A.tile_atom_begin = s.d_tile_atom_begin.p + lc.first_tile;
+        A.tile_atoms = s.d_tile_atoms.p;
+        A.n_tiles = lc.n_tiles;
+        A.sub_delta = env.sub_delta;
+        A.damping = env.damping;
+        A.follow_compliance = env.follow_c;
+        A.collision_compliance = env.collision_c;
+        A.overlap_factor = s.cfg.collision_overlap_factor;
+        A.cell_size = env.cell;
+        A.eps = s.cfg.eps;
+        A.budget = env.budget;
+        A.single_tile = (s.single_tile || h->opt_force_single) ? 1 : 0;
+        A.n_substeps = S;
+        A.n_collision_steps = C;
+        A.nmax = lc.nmax;
+        A.amax = lc.amax;
+        A.ht = lc.ht;
+        A.lcap = lc.lcap;
+        A.status = s.d_status;
+        hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3(EGG_WAVE), lc.lds, s.stream, A);
+        HIP_TRY(h, hipGetLastError());
+        h->stats.kernel_launches++;
+    }
+    if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev1, s.stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_status, s.d_status, sizeof(EggStatus), hipMemcpyDeviceToHost, s.stream));
+    return EGG_OK;
+}
+
+int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
+    const double sub_delta = std::max(delta / S, h->sys[0].cfg.eps);
+    if (C == 1 && S >= 3)
+        return fail(h, EGG_ERR_UNSUPPORTED,
+                    "n_collision_steps == 1 with n_substeps >= 3 (hash lists accumulating over more than one "
+                    "un-cleared pass) is not implemented on the device path");
+    Env env[2];
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        env[w] = make_env(s.cfg, sub_delta, s.n);
+        // mass / radius follow a config change at the next step (L:1731-1744, L:1420-1430)
+        bool upd_mass = !s.has_env || s.cfg.min_mass != s.env_min_mass || s.cfg.max_mass != s.env_max_mass;
+        bool upd_radius = !s.has_env || s.cfg.min_radius != s.env_min_radius || s.cfg.max_radius != s.env_max_radius;
+        if (s.has_env && (upd_mass || upd_radius) && s.n > 0) {
+            const int threads = 256;
+            hipLaunchKernelGGL(egg_rederive_kernel, dim3((unsigned)((s.n + threads - 1) / threads)), dim3(threads), 0,
+                               s.stream, s.mass_t.p, s.inv_mass.p, s.radius.p, (int)s.n, upd_mass ? 1 : 0,
+                               s.cfg.min_mass, s.cfg.max_mass, upd_radius ? 1 : 0, s.cfg.min_radius, s.cfg.max_radius);
+            HIP_TRY(h, hipGetLastError());
+            h->stats.kernel_launches++;
+        }
+        s.has_env = true;
+        s.env_min_mass = s.cfg.min_mass;
+        s.env_max_mass = s.cfg.max_mass;
+        s.env_min_radius = s.cfg.min_radius;
+        s.env_max_radius = s.cfg.max_radius;
+        if (env[w].cell != s.tiled_cell_size) {
+            s.tiling_dirty = true;
+            s.aabb_valid = false;
+        }
+    }
+
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 24) return fail(h, EGG_ERR_INTERNAL, "step did not validate after %d attempts", attempt);
+        for (int w = 0; w < 2; ++w) {
+            System &s = h->sys[w];
+            int rc = upload_atoms(h, w);
+            if (rc != EGG_OK) return rc;
+            if (s.tiling_dirty) {
+                rc = retile(h, w);
+                if (rc != EGG_OK) return rc;
+            }
+        }
+        for (int w = 0; w < 2; ++w) {
+            int rc = launch_type(h, w, env[w], S, C);
+            if (rc != EGG_OK) return rc;
+        }
+        bool redo = false;
+        double ms = 0;
+        for (int w = 0; w < 2; ++w) {
+            System &s = h->sys[w];
+            if (s.n == 0 || s.classes.empty()) continue;
+            HIP_TRY(h, hipStreamSynchronize(s.stream));
+            if (h->opt_timing) {
+                float t = 0;
+                HIP_TRY(h, hipEventElapsedTime(&t, s.ev0, s.ev1));
+                ms = std::max(ms, (double)t);
+            }
+            const EggStatus &st = *s.h_status;
+            if (st.fail_overflow) {
+                // more visited pairs than the launch had list room for: grow and re-run
+                s.list_min = std::max<size_t>(s.list_min, (size_t)(st.max_list * 5 / 4 + 64));
+                s.list_factor *= 1.5;
+                if (s.list_min > (size_t)kMaxListEntries)
+                    return fail(h, EGG_ERR_UNSUPPORTED, "a tile visits %llu pairs in one pass; limit is %d",
+                                (unsigned long long)st.max_list, kMaxListEntries);
+                s.tiling_dirty = true;
+                redo = true;
+                continue;
+            }
+            if (st.fail_claim || st.fail_range) {
+                // a particle left its claimed cells: tiles were not provably independent.  Widen the
+                // claims a little (wide claims merge neighbours into one tile) and re-run the step.
+                s.margin = std::min(s.margin + std::max(2, s.margin / 2), 4096);
+                s.tiling_dirty = true;
+                s.aabb_valid = false;
+                redo = true;
+                continue;
+            }
+            if (st.fail_stall) return fail(h, EGG_ERR_INTERNAL, "pair scheduler stalled (type %d)", w);
+            const bool single = s.single_tile || h->opt_force_single;
+            if (!single) {
+                // budget check (L:1657-1658): the return can only fire if some pass visits more than
+                // ceil(budget) pairs; then the visiting order across tiles matters -> exact mode
+                const double m = std::max(1.0, std::ceil(env[w].budget));
+                const int np = std::min(S * C, EGG_MAX_PASSES);
+                for (int p = 0; p < np; ++p)
+                    if ((double)st.visits[p] > m) {
+                        s.single_tile = 1;
+                        s.uncut_streak = 0;
+                        s.tiling_dirty = true;
+                        redo = true;
+                        break;
+                    }
+            }
+        }
+        if (redo) {
+            h->stats.redo_steps++;
+            continue;
+        }
+        // commit
+        for (int w = 0; w < 2; ++w) {
+            System &s = h->sys[w];
+            if (s.n == 0 || s.classes.empty()) continue;
+            const EggStatus &st = *s.h_status;
+            s.cur ^= 1;
+            const int np = std::min(S * C, EGG_MAX_PASSES);
+            for (int p = 0; p < np; ++p) h->stats.pair_solves += (int64_t)st.visits[p];
+            h->stats.follow_solves += s.n * S;
+            s.aabb_valid = false;  // d_atom_aabb now holds end-of-step cells; fetched on demand
+            s.aabb_on_device = true;
+            if (st.min_slack < s.margin) {
+                // some particle has used part of its margin: re-tile around the new positions
+                s.tiling_dirty = true;
+            }
+            if (s.margin > h->opt_margin) {  // widened after a failed check: relax again
+                s.margin -= 1;
+                s.tiling_dirty = true;
+            }
+            if (s.single_tile && !h->opt_force_single) {
+                // leave exact mode once the budget has not cut for a while and cannot bind by size
+                s.uncut_streak = st.was_cut ? 0 : s.uncut_streak + 1;
+                if (s.uncut_streak >= 8) {
+                    s.single_tile = 0;
+                    s.tiling_dirty = true;
+                }
+            }
+            h->stats.single_tile[w] = s.single_tile;
+        }
+        h->stats.last_step_kernel_ms = ms;
+        h->stats.steps++;
+        return EGG_OK;
+    }
+}
+
+int fetch_end_aabb(egg_handle *h, System &s) {
+    // after a committed step d_atom_aabb holds the atoms' cells at the new positions
+    const size_t na = s.atoms.size();
+    s.aabb.resize(na);
+    if (na) {
+        HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), s.d_atom_aabb.p, na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipStreamSynchronize(s.stream));
+    }
+    s.aabb_valid = true;
+    return EGG_OK;
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+
+extern "C" {
+
+int egg_default_config(int which, egg_config *cfg) {  // simulation_handler_default_config.lua:1-70
+    if (!cfg || (which != EGG_WHITE && which != EGG_YOLK)) return EGG_ERR_INVALID_ARGUMENT;
+    const double base_damping = 0.1, particle_radius = 4, base_mass = 1;
+    cfg->damping = base_damping;
+    cfg->follow_strength = 1 - 0.004;
+    cfg->collision_overlap_factor = 2;
+    cfg->min_mass = base_mass;
+    cfg->min_radius = particle_radius;
+    cfg->max_radius = particle_radius;
+    if (which == EGG_WHITE) {
+        cfg->cohesion_strength = 1 - 0.2;
+        cfg->cohesion_interaction_distance_factor = 2;
+        cfg->collision_strength = 1 - 0.0025;
+        cfg->max_mass = base_mass * 1.8;
+    } else {
+        cfg->cohesion_strength = 1 - 0.002;
+        cfg->cohesion_interaction_distance_factor = 3;
+        cfg->collision_strength = 1 - 0.001;
+        cfg->max_mass = base_mass * 1.35;
+    }
+    cfg->max_collision_fraction = 0.05;   // L:448
+    cfg->mass_distribution_variance = 4;  // L:447
+    cfg->eps = 1e-8;                      // math.lua:2
+    return EGG_OK;
+}
+
+const char *egg_last_error(const egg_handle *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_handle **out) {
+    if (!white || !out) return fail(nullptr, EGG_ERR_INVALID_ARGUMENT, "egg_create: null argument");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, EGG_ERR_NO_DEVICE, "no HIP device available (%s); libeggsim has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return fail(nullptr, EGG_ERR_NO_DEVICE, "device ordinal %d out of range (0..%d)", device, count - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, EGG_ERR_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    egg_handle *h = new egg_handle();
+    h->device = device;
+    (void)hipGetDeviceProperties(&h->prop, device);
+    h->sys[0].cfg = *white;
+    h->sys[1].cfg = yolk ? *yolk : *white;
+    e = hipFuncSetAttribute((const void *)egg_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(nullptr, EGG_ERR_DEVICE, "cannot raise the step kernel's LDS limit: %s", hipGetErrorString(e));
+    }
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        s.margin = h->opt_margin;
+        bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreate(&s.ev0) == hipSuccess && hipEventCreate(&s.ev1) == hipSuccess &&
+                  hipMalloc((void **)&s.d_status, sizeof(EggStatus)) == hipSuccess &&
+                  hipHostMalloc((void **)&s.h_status, sizeof(EggStatus), hipHostMallocDefault) == hipSuccess;
+        if (!ok) {
+            egg_destroy(h);
+            return fail(nullptr, EGG_ERR_DEVICE, "device resource allocation failed");
+        }
+        memset(s.h_status, 0, sizeof(EggStatus));
+    }
+    // the reference primes its environments with _step(0, 1, 1) on zero particles (L:562); the
+    // observable effect is that mass/radius of particles added later are not re-derived
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        s.has_env = true;
+        s.env_min_mass = s.cfg.min_mass;
+        s.env_max_mass = s.cfg.max_mass;
+        s.env_min_radius = s.cfg.min_radius;
+        s.env_max_radius = s.cfg.max_radius;
+    }
+    *out = h;
+    return EGG_OK;
+}
+
+void egg_destroy(egg_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.d_status) (void)hipFree(s.d_status);
+        if (s.h_status) (void)hipHostFree(s.h_status);
+        if (s.ev0) (void)hipEventDestroy(s.ev0);
+        if (s.ev1) (void)hipEventDestroy(s.ev1);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete h;
+}
+
+int egg_set_config(egg_handle *h, int which, const egg_config *cfg) {
+    if (!h || !cfg || (which != EGG_WHITE && which != EGG_YOLK)) return EGG_ERR_INVALID_ARGUMENT;
+    h->sys[which].cfg = *cfg;
+    return EGG_OK;
+}
+
+int egg_get_config(const egg_handle *h, int which, egg_config *cfg) {
+    if (!h || !cfg || (which != EGG_WHITE && which != EGG_YOLK)) return EGG_ERR_INVALID_ARGUMENT;
+    *cfg = h->sys[which].cfg;
+    return EGG_OK;
+}
+
+int egg_add_many(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
+                 double yolk_radius, int64_t white_n, int64_t yolk_n, int64_t *out_ids) {
+    if (!h || n < 0 || (n > 0 && (!xs || !ys))) return EGG_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(h->device);
+    const egg_config &wc = h->sys[0].cfg, &yc = h->sys[1].cfg;
+    // L:33-58
+    double white_particle_radius = mixd(wc.min_radius, wc.max_radius, 0.5);
+    double yolk_particle_radius = mixd(yc.min_radius, yc.max_radius, 0.5);
+    if (std::isnan(white_radius)) white_radius = white_particle_radius * 15;
+    if (std::isnan(yolk_radius)) yolk_radius = white_radius * (10.0 / 50);
+    if (white_n <= 0)
+        white_n = (int64_t)std::ceil((kPi * (white_radius * white_radius)) /
+                                     (kPi * (white_particle_radius * white_particle_radius)));
+    if (yolk_n <= 0)
+        yolk_n = (int64_t)std::ceil((kPi * (yolk_radius * yolk_radius)) /
+                                    (kPi * (yolk_particle_radius * yolk_particle_radius)));
+    // L:71-85
+    if (!(white_radius > 0)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.add: white radius cannot be 0 or negative");
+    if (!(yolk_radius > 0)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.add: yolk radius cannot be 0 or negative");
+    if (white_n <= 1) return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.add: white particle count cannot be 1 or negative");
+    if (yolk_n <= 1) return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.add: yolk particle count cannot be 1 or negative");
+    for (int64_t k = 0; k < n; ++k)
+        if (!std::isfinite(xs[k]) || !std::isfinite(ys[k]))
+            return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.add: position is not a finite number");
+    if (h->sys[0].n + white_n * n > 2000000000ll || h->sys[1].n + yolk_n * n > 2000000000ll)
+        return fail(h, EGG_ERR_UNSUPPORTED, "more than 2e9 particles of one type");
+    if (n == 0) return EGG_OK;
+
+    ParticleTemplate tw, ty;
+    make_template(wc, white_radius, white_n, tw);
+    make_template(yc, yolk_radius, yolk_n, ty);
+    int rc = append_particles(h, h->sys[0], tw, n, xs, ys);
+    if (rc != EGG_OK) return rc;
+    rc = append_particles(h, h->sys[1], ty, n, xs, ys);
+    if (rc != EGG_OK) return rc;
+    for (int64_t k = 0; k < n; ++k) {
+        Batch b;
+        b.id = (int64_t)h->batches.size() + 1;
+        b.alive = true;
+        b.target_x = xs[k];
+        b.target_y = ys[k];
+        b.white_radius = white_radius;
+        b.yolk_radius = yolk_radius;
+        b.n[0] = white_n;
+        b.n[1] = yolk_n;
+        h->batches.push_back(b);
+        h->n_alive++;
+        if (out_ids) out_ids[k] = b.id;
+    }
+    if (white_n < 10 || yolk_n < 5) {  // L:114-120: warning only
+        fail(h, EGG_WARN_FEW_PARTICLES,
+             "In SimulationHandler.add: only %lld white / %lld yolk particles will be created; consider "
+             "increasing the radius or decreasing the particle size",
+             (long long)white_n, (long long)yolk_n);
+        return EGG_WARN_FEW_PARTICLES;
+    }
+    return EGG_OK;
+}
+
+int egg_add(egg_handle *h, double x, double y, double white_radius, double yolk_radius, int64_t white_n,
+            int64_t yolk_n, int64_t *out_id) {
+    return egg_add_many(h, 1, &x, &y, white_radius, yolk_radius, white_n, yolk_n, out_id);
+}
+
+int egg_remove(egg_handle *h, int64_t id) {  // L:140-155, L:1037-1106
+    if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    Batch *b = find_batch(h, id);
+    if (!b) return fail(h, EGG_WARN_UNKNOWN_ID, "In SimulationHandler.remove: no batch with id `%lld`", (long long)id);
+    (void)hipSetDevice(h->device);
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        int rc = upload_atoms(h, w);  // make sure s.atoms reflects the current layout
+        if (rc != EGG_OK) return rc;
+        const Atom *at = nullptr;
+        for (const Atom &a : s.atoms)
+            if (a.batch == (int32_t)(id - 1)) at = &a;
+        if (!at) return fail(h, EGG_ERR_INTERNAL, "egg_remove: atom not found");
+        s.aabb_on_device = false;
+        // order-preserving compaction: shift the tail down over the removed range
+        const size_t from = (size_t)at->offset + (size_t)at->count, tail = (size_t)s.n - from;
+        if (tail) {
+            DevBuf<double> tmp;
+            HIP_TRY(h, tmp.reserve(tail, false, s.stream));
+            double *arrays[] = {s.x[0].p, s.x[1].p, s.y[0].p, s.y[1].p, s.vx[0].p, s.vx[1].p, s.vy[0].p,
+                                s.vy[1].p, s.inv_mass.p, s.radius.p, s.mass_t.p};
+            for (double *a : arrays) {
+                HIP_TRY(h, hipMemcpyAsync(tmp.p, a + from, tail * 8, hipMemcpyDeviceToDevice, s.stream));
+                HIP_TRY(h, hipMemcpyAsync(a + at->offset, tmp.p, tail * 8, hipMemcpyDeviceToDevice, s.stream));
+            }
+            HIP_TRY(h, hipStreamSynchronize(s.stream));
+        }
+        s.n -= at->count;
+        s.atoms_dirty = s.tiling_dirty = true;
+        s.aabb_valid = false;
+    }
+    b->alive = false;
+    h->n_alive--;
+    return EGG_OK;
+}
+
+int egg_set_target(egg_handle *h, int64_t id, double x, double y) {  // L:254-264
+    if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    Batch *b = find_batch(h, id);
+    if (!b)
+        return fail(h, EGG_WARN_UNKNOWN_ID, "In SimulationHandler.set_target_position: no batch with id `%lld`",
+                    (long long)id);
+    b->target_x = x;
+    b->target_y = y;
+    h->sys[0].targets_dirty = h->sys[1].targets_dirty = true;
+    return EGG_OK;
+}
+
+int egg_set_targets_many(egg_handle *h, int64_t n, const int64_t *ids, const double *xs, const double *ys) {
+    if (!h || n < 0 || (n > 0 && (!ids || !xs || !ys))) return EGG_ERR_INVALID_ARGUMENT;
+    int rc = EGG_OK;
+    for (int64_t k = 0; k < n; ++k) {
+        int r = egg_set_target(h, ids[k], xs[k], ys[k]);
+        if (r != EGG_OK) rc = r;
+    }
+    return rc;
+}
+
+int egg_get_target(const egg_handle *h, int64_t id, double *x, double *y) {  // L:268-278
+    if (!h || !x || !y) return EGG_ERR_INVALID_ARGUMENT;
+    const Batch *b = find_batch(h, id);
+    if (!b)
+        return fail(const_cast<egg_handle *>(h), EGG_ERR_UNKNOWN_ID,
+                    "In SimulationHandler.get_target_position: no batch with id `%lld`", (long long)id);
+    *x = b->target_x;
+    *y = b->target_y;
+    return EGG_OK;
+}
+
+int egg_step(egg_handle *h, double delta, int32_t n_substeps, int32_t n_collision_steps) {
+    if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    if (n_substeps < 1 || n_collision_steps < 1 || std::isnan(delta))
+        return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_step: invalid arguments");
+    (void)hipSetDevice(h->device);
+    return do_step(h, delta, n_substeps, n_collision_steps);
+}
+
+int egg_update(egg_handle *h, double delta, double step_delta, int32_t n_substeps, int32_t n_collision_steps,
+               int32_t *out_n_steps) {  // L:168-222
+    if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    if (out_n_steps) *out_n_steps = 0;
+    if (std::isnan(delta)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.update: `delta` is not a number");
+    if (step_delta < 0 || std::isnan(step_delta))
+        return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.update: `step_delta` is not a number > 0");
+    if (step_delta == 0)  // the reference would loop forever here (elapsed >= 0 always holds)
+        return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.update: `step_delta` is 0");
+    if (n_substeps < 1)
+        return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.update: `n_substeps` is not a number > 0");
+    if (n_collision_steps < 1)
+        return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.update: `n_collision_steps` is not a number > 0");
+    (void)hipSetDevice(h->device);
+    h->elapsed = h->elapsed + delta;  // L:200
+    const double step = step_delta;
+    int n_steps = 0;
+    const double max_n_steps = std::max(4.0, 4 * std::ceil((1.0 / 60) / step_delta));  // L:203
+    while (h->elapsed >= step) {
+        int rc = do_step(h, step, n_substeps, n_collision_steps);
+        if (rc != EGG_OK) return rc;
+        h->elapsed = h->elapsed - step;
+        n_steps = n_steps + 1;
+        if (n_steps > max_n_steps) {  // L:208-213: death-spiral guard
+            h->elapsed = 0;
+            break;
+        }
+    }
+    h->interpolation_alpha = clampd(h->elapsed / step, 0, 1);  // L:216
+    if (out_n_steps) *out_n_steps = n_steps;
+    return EGG_OK;
+}
+
+int egg_synchronize(egg_handle *h) {
+    if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(h->device);
+    for (int w = 0; w < 2; ++w) HIP_TRY(h, hipStreamSynchronize(h->sys[w].stream));
+    return EGG_OK;
+}
+
+int egg_get_positions_many(egg_handle *h, int64_t n, const int64_t *ids, double *xs, double *ys) {
+    if (!h || n < 0 || (n > 0 && (!ids || !xs || !ys))) return EGG_ERR_INVALID_ARGUMENT;
+    if (n == 0) return EGG_OK;
+    (void)hipSetDevice(h->device);
+    for (int w = 0; w < 2; ++w) {
+        int rc = upload_atoms(h, w);
+        if (rc != EGG_OK) return rc;
+    }
+    // atom of each live batch: both types list live batches in the same (creation) order
+    std::vector<int32_t> atom_of_batch(h->batches.size(), -1);
+    for (size_t k = 0; k < h->sys[0].atoms.size(); ++k) atom_of_batch[(size_t)h->sys[0].atoms[k].batch] = (int32_t)k;
+    std::vector<int32_t> wo((size_t)n), wc((size_t)n), yo((size_t)n), yc((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        const Batch *b = find_batch(h, ids[k]);
+        if (!b)
+            return fail(h, EGG_ERR_UNKNOWN_ID, "In SimulationHandler.get_position: no batch with id `%lld`",
+                        (long long)ids[k]);
+        int32_t a = atom_of_batch[(size_t)ids[k] - 1];
+        wo[(size_t)k] = h->sys[0].atoms[(size_t)a].offset;
+        wc[(size_t)k] = h->sys[0].atoms[(size_t)a].count;
+        yo[(size_t)k] = h->sys[1].atoms[(size_t)a].offset;
+        yc[(size_t)k] = h->sys[1].atoms[(size_t)a].count;
+    }
+    System &W = h->sys[0], &Y = h->sys[1];
+    DevBuf<int32_t> d_idx;
+    DevBuf<double> d_out;
+    HIP_TRY(h, d_idx.reserve((size_t)n * 4, false, W.stream));
+    HIP_TRY(h, d_out.reserve((size_t)n * 2, false, W.stream));
+    HIP_TRY(h, hipMemcpy(d_idx.p, wo.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_idx.p + n, wc.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_idx.p + 2 * n, yo.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_idx.p + 3 * n, yc.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipStreamSynchronize(Y.stream));
+    const int threads = 64;
+    hipLaunchKernelGGL(egg_centroid_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, W.stream,
+                       W.x[W.cur].p, W.y[W.cur].p, Y.x[Y.cur].p, Y.y[Y.cur].p, d_idx.p, d_idx.p + n, d_idx.p + 2 * n,
+                       d_idx.p + 3 * n, (int)n, d_out.p, d_out.p + n);
+    HIP_TRY(h, hipGetLastError());
+    h->stats.kernel_launches++;
+    HIP_TRY(h, hipMemcpyAsync(xs, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, W.stream));
+    HIP_TRY(h, hipMemcpyAsync(ys, d_out.p + n, (size_t)n * 8, hipMemcpyDeviceToHost, W.stream));
+    HIP_TRY(h, hipStreamSynchronize(W.stream));
+    return EGG_OK;
+}
+
+int egg_get_position(egg_handle *h, int64_t id, double *x, double *y) {
+    return egg_get_positions_many(h, 1, &id, x, y);
+}
+
+int egg_get_n_particles(const egg_handle *h, int64_t id, int64_t *n_white, int64_t *n_yolk) {  // L:409-419
+    if (!h || !n_white || !n_yolk) return EGG_ERR_INVALID_ARGUMENT;
+    if (id < 0) {
+        *n_white = h->sys[0].n;
+        *n_yolk = h->sys[1].n;
+        return EGG_OK;
+    }
+    const Batch *b = find_batch(h, id);
+    if (!b)
+        return fail(const_cast<egg_handle *>(h), EGG_ERR_UNKNOWN_ID,
+                    "In SimulationHandler:get_n_particles: no batch with id `%lld`", (long long)id);
+    *n_white = b->n[0];
+    *n_yolk = b->n[1];
+    return EGG_OK;
+}
+
+int egg_list_ids(const egg_handle *h, int64_t cap, int64_t *ids, int64_t *n) {  // L:399-405
+    if (!h || !n) return EGG_ERR_INVALID_ARGUMENT;
+    int64_t k = 0;
+    for (const Batch &b : h->batches)
+        if (b.alive) {
+            if (ids && k < cap) ids[k] = b.id;
+            ++k;
+        }
+    *n = k;
+    return EGG_OK;
+}
+
+int egg_get_elapsed(const egg_handle *h, double *elapsed, double *interpolation_alpha) {
+    if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    if (elapsed) *elapsed = h->elapsed;
+    if (interpolation_alpha) *interpolation_alpha = h->interpolation_alpha;
+    return EGG_OK;
+}
+
+int egg_download_particles(egg_handle *h, int which, int field, double *dst, int64_t cap) {
+    if (!h || !dst || (which != EGG_WHITE && which != EGG_YOLK) || field < 0 || field >= EGG_N_FIELDS)
+        return EGG_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(h->device);
+    System &s = h->sys[which];
+    if (cap < s.n) return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_download_particles: buffer holds %lld of %lld particles",
+                               (long long)cap, (long long)s.n);
+    if (s.n == 0) return EGG_OK;
+    const double *src = nullptr;
+    switch (field) {
+        case EGG_FIELD_X: src = s.x[s.cur].p; break;
+        case EGG_FIELD_Y: src = s.y[s.cur].p; break;
+        case EGG_FIELD_VX: src = s.vx[s.cur].p; break;
+        case EGG_FIELD_VY: src = s.vy[s.cur].p; break;
+        case EGG_FIELD_LAST_X: src = s.x[s.cur ^ 1].p; break;  // positions at the start of the last _step
+        case EGG_FIELD_LAST_Y: src = s.y[s.cur ^ 1].p; break;
+        case EGG_FIELD_RADIUS: src = s.radius.p; break;
+        case EGG_FIELD_INV_MASS: src = s.inv_mass.p; break;
+        case EGG_FIELD_MASS_T: src = s.mass_t.p; break;
+        default: break;
+    }
+    if (field == EGG_FIELD_BATCH_ID) {
+        int rc = upload_atoms(h, which);
+        if (rc != EGG_OK) return rc;
+        for (const Atom &a : s.atoms)
+            for (int32_t k = 0; k < a.count; ++k) dst[a.offset + k] = (double)h->batches[(size_t)a.batch].id;
+        return EGG_OK;
+    }
+    HIP_TRY(h, hipMemcpyAsync(dst, src, (size_t)s.n * 8, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipStreamSynchronize(s.stream));
+    return EGG_OK;
+}
+
+int egg_get_stats(egg_handle *h, egg_stats *out) {
+    if (!h || !out) return EGG_ERR_INVALID_ARGUMENT;
+    *out = h->stats;
+    return EGG_OK;
+}
+
+int egg_set_option(egg_handle *h, int option, double value) {
+    if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    switch (option) {
+        case EGG_OPT_CLAIM_MARGIN_CELLS:
+            if (!(value >= 1 && value <= 4096)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "margin must be in [1, 4096]");
+            h->opt_margin = (int)value;
+            for (int w = 0; w < 2; ++w) {
+                h->sys[w].margin = h->opt_margin;
+                h->sys[w].tiling_dirty = true;
+            }
+            return EGG_OK;
+        case EGG_OPT_TILE_TARGET_PARTICLES:
+            if (!(value >= 0 && value <= kMaxTileParticles)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "tile target out of range");
+            h->opt_tile_target = (int)value;
+            h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
+            return EGG_OK;
+        case EGG_OPT_TIMING:
+            h->opt_timing = value != 0;
+            return EGG_OK;
+        case EGG_OPT_FORCE_SINGLE_TILE:
+            h->opt_force_single = value != 0;
+            h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
+            return EGG_OK;
+        default:
+            return fail(h, EGG_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+/*
+ * eggsim.h -- C ABI of libeggsim.so: the MI355X (gfx950) implementation of the
+ * XPBD particle step of Clemapfel/egg_fluid_simulation.
+ *
+ * The reference has no native/FFI layer; its boundary is the Lua class
+ * `SimulationHandler` (simulation_handler.lua:9-419).  Every entry point below
+ * is what a LuaJIT `ffi.cdef` wrapper of that class binds for the solver path
+ * (the wrapper is lua/egg_fluid_simulation/simulation_handler.lua; the stub a
+ * maintainer adds is shown in INTEGRATION.md).  Reference citations are
+ * file:line into /root/reference/simulation_handler.lua ("L:").
+ *
+ * Conventions
+ *  - plain C types only; scalars are double / int64_t / int32_t;
+ *  - every call returns an int status: EGG_OK, a positive "warning class"
+ *    status where the reference prints a warning and carries on, or a negative
+ *    "error class" status where the reference throws (log.error);
+ *  - egg_last_error(h) gives the message of the last non-OK status;
+ *  - arrays are caller-owned and copied during the call;
+ *  - one handle is used by one thread at a time (the reference is
+ *    single-threaded, non-reentrant);
+ *  - there is NO CPU fallback: creating a handle without a usable HIP device
+ *    fails with EGG_ERR_NO_DEVICE.
+ */
+#ifndef EGGSIM_H
+#define EGGSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGGSIM_ABI_VERSION 1
+
+typedef struct egg_handle egg_handle;
+
+enum {
+    EGG_OK = 0,
+    EGG_WARN_UNKNOWN_ID = 1,     /* set_target_position / remove on a missing id: warning, no throw (L:145, L:259) */
+    EGG_WARN_FEW_PARTICLES = 2,  /* add: white_n < 10 or yolk_n < 5 (L:114-120); the batch IS created */
+    EGG_ERR_UNKNOWN_ID = -1,     /* get_position / get_target_position / get_n_particles (L:273, L:286, L:415) */
+    EGG_ERR_INVALID_ARGUMENT = -2, /* the reference's log.error paths in add/update (L:71-85, L:184-197) */
+    EGG_ERR_NO_DEVICE = -3,
+    EGG_ERR_DEVICE = -4,         /* a HIP call failed; message has the HIP error string */
+    EGG_ERR_UNSUPPORTED = -5,    /* a configuration the device path does not implement yet */
+    EGG_ERR_INTERNAL = -6
+};
+
+enum { EGG_WHITE = 0, EGG_YOLK = 1 };
+
+/* The solver-relevant keys of a white/yolk config table (L:1152-1249, defaults in
+ * simulation_handler_default_config.lua:10-68) plus the three hidden constants
+ * (L:447-448, math.lua:2).  Values are taken as already validated/clamped by the
+ * host wrapper (_load_config, L:1253-1320); the library re-applies the clamps the
+ * step itself applies (L:1338, L:1768). */
+typedef struct {
+    double damping;
+    double follow_strength;
+    double cohesion_strength;
+    double cohesion_interaction_distance_factor;
+    double collision_strength;
+    double collision_overlap_factor;
+    double min_mass, max_mass;
+    double min_radius, max_radius;
+    double max_collision_fraction;     /* 0.05 */
+    double mass_distribution_variance; /* 4 */
+    double eps;                        /* 1e-8 */
+} egg_config;
+
+/* fills *cfg with the reference defaults for `which` */
+int egg_default_config(int which, egg_config *cfg);
+
+/* SimulationHandler(white_config, yolk_config) (L:425-459).  yolk == NULL means
+ * "same as white" (L:426).  device = HIP device ordinal. */
+int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_handle **out);
+void egg_destroy(egg_handle *h);
+const char *egg_last_error(const egg_handle *h); /* h may be NULL: last create error */
+
+/* set_white_config / set_yolk_config, get_*_config (L:226-248) */
+int egg_set_config(egg_handle *h, int which, const egg_config *cfg);
+int egg_get_config(const egg_handle *h, int which, egg_config *cfg);
+
+/* add(x, y, white_radius, yolk_radius, ..., white_n, yolk_n) -> id (L:27-135).
+ * Pass NaN for a radius and <= 0 for a count to get the reference's defaults
+ * (L:41-58).  Colors are render attributes and stay on the host side. */
+int egg_add(egg_handle *h, double x, double y, double white_radius, double yolk_radius,
+            int64_t white_n, int64_t yolk_n, int64_t *out_id);
+/* n batches with identical radii in one call (bulk form for 10^4..10^5 batches) */
+int egg_add_many(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
+                 double yolk_radius, int64_t white_n, int64_t yolk_n, int64_t *out_ids);
+/* remove(id) (L:140-155, L:1037-1106) */
+int egg_remove(egg_handle *h, int64_t id);
+
+/* set_target_position / get_target_position (L:254-278) */
+int egg_set_target(egg_handle *h, int64_t id, double x, double y);
+int egg_set_targets_many(egg_handle *h, int64_t n, const int64_t *ids, const double *xs, const double *ys);
+int egg_get_target(const egg_handle *h, int64_t id, double *x, double *y);
+
+/* update(delta, step_delta, n_substeps, n_collision_steps) (L:168-222): runs the
+ * fixed-step accumulator; *out_n_steps = number of _step calls made. */
+int egg_update(egg_handle *h, double delta, double step_delta, int32_t n_substeps,
+               int32_t n_collision_steps, int32_t *out_n_steps);
+/* _step(delta, n_sub_steps, n_collision_steps) directly (L:1722) */
+int egg_step(egg_handle *h, double delta, int32_t n_substeps, int32_t n_collision_steps);
+/* blocks until all device work of this handle is finished */
+int egg_synchronize(egg_handle *h);
+
+/* get_position(id) -> mean particle position of the batch (L:281-295, L:1134-1148) */
+int egg_get_position(egg_handle *h, int64_t id, double *x, double *y);
+int egg_get_positions_many(egg_handle *h, int64_t n, const int64_t *ids, double *xs, double *ys);
+
+/* get_n_particles(id) / get_n_particles() with id < 0 (L:409-419) */
+int egg_get_n_particles(const egg_handle *h, int64_t id, int64_t *n_white, int64_t *n_yolk);
+/* list_ids (L:399-405): ids in creation order; returns the count in *n, copies min(*n, cap) ids */
+int egg_list_ids(const egg_handle *h, int64_t cap, int64_t *ids, int64_t *n);
+int egg_get_elapsed(const egg_handle *h, double *elapsed, double *interpolation_alpha);
+
+/* particle fields for egg_download_particles */
+enum {
+    EGG_FIELD_X = 0, EGG_FIELD_Y, EGG_FIELD_VX, EGG_FIELD_VY, EGG_FIELD_LAST_X, EGG_FIELD_LAST_Y,
+    EGG_FIELD_RADIUS, EGG_FIELD_INV_MASS, EGG_FIELD_MASS_T, EGG_FIELD_BATCH_ID, EGG_N_FIELDS
+};
+/* copies one field of every particle of `which`, in particle-index order, into dst
+ * (doubles).  x,y,last_x,last_y,vx,vy,radius form the reference's instanced-draw
+ * record (L:513-517, L:744-813). */
+int egg_download_particles(egg_handle *h, int which, int field, double *dst, int64_t cap);
+
+/* counters of the device path, cumulative since creation */
+typedef struct {
+    int64_t steps;           /* _step calls executed */
+    int64_t pair_solves;     /* visited pairs = n_collided increments (L:1657) */
+    int64_t follow_solves;   /* follow-constraint evaluations (N * S per step) */
+    int64_t kernel_launches;
+    int64_t retiles;         /* host re-clusterings of particles into tiles */
+    int64_t redo_steps;      /* steps re-run after a failed independence/budget check */
+    int64_t n_tiles[2];      /* current tile count per type */
+    int64_t max_tile_particles[2];
+    double last_step_kernel_ms; /* device time of the step kernels of the most recent _step (HIP events) */
+    int64_t single_tile[2];  /* 1 if that type currently runs in exact-budget single-tile mode */
+} egg_stats;
+int egg_get_stats(egg_handle *h, egg_stats *out);
+
+/* tuning knobs (not part of the reference surface) */
+enum {
+    EGG_OPT_CLAIM_MARGIN_CELLS = 0, /* initial margin around an atom's cells when tiles are formed */
+    EGG_OPT_TILE_TARGET_PARTICLES,  /* pack independent islands into tiles up to this size (0 = one island per tile) */
+    EGG_OPT_TIMING,                 /* 1: record HIP events around the step kernels */
+    EGG_OPT_FORCE_SINGLE_TILE       /* 1: always run each type as one tile (exact budget path) */
+};
+int egg_set_option(egg_handle *h, int option, double value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -45,36 +45,41 @@ struct EggStepArgs {
     int32_t single_tile;       // 1: this launch is one tile holding every particle -> exact budget handling
     int32_t n_substeps, n_collision_steps;
     // LDS geometry of this launch
-    int32_t nmax;   // particles per tile (capacity)
-    int32_t amax;   // atoms per tile (capacity)
-    int32_t ht;     // cell hash table size, power of two
-    int32_t lcap;   // visit-list entries per pass (capacity)
+    int32_t nmax;      // particles per tile (capacity)
+    int32_t amax;      // atoms per tile (capacity)
+    int32_t ccap;      // cells: dense grid capacity (use_grid) or hash slots (power of two)
+    int32_t use_grid;  // 1: cells are a dense grid over the tile's claim box, 0: open-addressing hash
+    int32_t lcap;      // visit-list entries per pass (capacity)
     EggStatus *status;
 };
 
-static inline size_t egg_align8(size_t v) { return (v + 7) & ~(size_t)7; }
+static inline size_t egg_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 // dynamic LDS bytes the step kernel carves for the geometry above (must match eggsim_step.hip)
-static inline size_t egg_step_lds_bytes(int nmax, int amax, int ht, int lcap) {
-    size_t n = (size_t)nmax, a = (size_t)amax, h = (size_t)ht, l = (size_t)lcap;
+static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_grid, int lcap, int single_tile) {
+    size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, l = (size_t)lcap;
     size_t b = 0;
-    b += 8 * n * 8;                 // x y px py vx vy w r
-    b += a * 3 * 8;                 // atx aty afd
-    b += egg_align8(2 * n * 4);     // ckey[2]
-    b += egg_align8(2 * h * 4);     // hkeys[2]
-    b += egg_align8(2 * h * 4);     // hmeta[2]
-    b += egg_align8(2 * (n + 1) * 4); // own_off[2]
-    b += egg_align8((n + 1) * 4);   // inc_off
-    b += egg_align8(n * 4);         // fill
-    b += egg_align8((n / 2 + 1) * 2 * 4); // queue[2]
-    b += egg_align8(a * 4 * 4);     // aclaim
-    b += egg_align8(a * 4 * 4);     // aaabb
-    b += egg_align8((a + 1) * 4);   // aoff
-    b += egg_align8(a * 4);         // abatch
-    b += egg_align8(16 * 4);        // scalars
-    b += egg_align8(2 * n * 2);     // hitems[2]
-    b += egg_align8(n * 2) * 6;     // pslot aslot ptr nlo nxt stamp
-    b += egg_align8(2 * l * 2);     // own_ent[2]
-    b += egg_align8(l * 2) * 2;     // inc_ent inc_tmp
+    b += 4 * egg_align16(n * 16);            // pos wr prev vel
+    b += 3 * egg_align16(a * 8);             // atx aty afd
+    b += egg_align16(2 * n * 4);             // ckey[2]
+    b += egg_align16(2 * c * 4);             // cell[2]
+    b += egg_align16(use_grid ? 0 : 2 * c * 4);  // hkeys[2]
+    b += egg_align16(2 * (n + 1) * 4);       // own_off[2]
+    b += egg_align16((n + 1) * 4);           // inc_off
+    b += 2 * egg_align16(n * 4);             // fill done
+    b += 2 * egg_align16(l * 4);             // own_pack inc_tmp
+    b += egg_align16(a * 4 * 4);             // aclaim
+    b += egg_align16((a + 1) * 4);           // aoff
+    b += egg_align16(a * 4);                 // abatch
+    b += egg_align16(16 * 4);                // scalars
+    b += egg_align16(2 * n * 2);             // hitems[2]
+    b += 3 * egg_align16(n * 2);             // pslot aslot nlo
+    b += egg_align16((single_tile ? 2 : 1) * l * 2);  // own_ent
     return b;
+}
+
+// threads of the workgroup that runs a tile of at most nmax particles (one thread per particle)
+static inline int egg_step_threads(int nmax) {
+    int t = (nmax + EGG_WAVE - 1) / EGG_WAVE * EGG_WAVE;
+    return t < EGG_WAVE ? EGG_WAVE : (t > 1024 ? 1024 : t);
 }

@@ -33,7 +33,7 @@ extern "C" __global__ void egg_centroid_kernel(const double *, const double *, c
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;
-constexpr size_t kLdsLimit = 160 * 1024;
+constexpr size_t kLdsMax = 160 * 1024;  // per CU on gfx950; what a workgroup may use is probed at create
 constexpr int kMaxTileParticles = 32000;  // 15-bit local indices in the kernel's pair sequences
 constexpr int kMaxListEntries = 60000;    // 16-bit round stamps in the DAG executor
 
@@ -89,7 +89,7 @@ struct Box {
 
 struct LaunchClass {  // tiles of similar size share a launch (uniform LDS geometry)
     int first_tile = 0, n_tiles = 0;
-    int nmax = 0, amax = 0, ht = 0, lcap = 0;
+    int nmax = 0, amax = 0, ccap = 0, use_grid = 0, lcap = 0;
     size_t lds = 0;
 };
 
@@ -113,7 +113,7 @@ struct System {  // one particle type
     int margin = 2;
     int single_tile = 0;  // exact-budget mode: everything in one tile
     int uncut_streak = 0;
-    double list_factor = 10.0;  // visit-list capacity per particle, grows on overflow
+    double list_factor = 6.0;  // visit-list capacity per particle, grows on overflow
     size_t list_min = 0;
     // environment of the previous step (L:1731-1744)
     bool has_env = false;
@@ -140,6 +140,7 @@ struct egg_handle {
     int opt_timing = 0;
     int opt_force_single = 0;
     hipDeviceProp_t prop{};
+    size_t lds_limit = 64 * 1024;  // dynamic LDS a step-kernel workgroup may use
 };
 
 namespace {
@@ -515,8 +516,12 @@ int retile(egg_handle *h, int which) {
         size_t t1 = t0;
         int64_t nmax = tiles[t0].particles;
         int amax = 0;
+        int64_t max_cells = 0;
         while (t1 < tiles.size() && tiles[t1].particles * 2 > nmax) {
             amax = std::max(amax, (int)tiles[t1].atoms.size());
+            // dense grid the kernel lays over the tile's claim box (see eggsim_step.hip, load tile)
+            const Box &bx = tiles[t1].box;
+            max_cells = std::max(max_cells, ((int64_t)bx.hi_x - bx.lo_x + 4) * ((int64_t)bx.hi_y - bx.lo_y + 4));
             ++t1;
         }
         LaunchClass lc;
@@ -524,18 +529,24 @@ int retile(egg_handle *h, int which) {
         lc.n_tiles = (int)(t1 - t0);
         lc.nmax = (int)((nmax + 7) & ~7ll);
         lc.amax = amax;
-        int ht = 64;
-        while (ht < lc.nmax + lc.nmax / 2) ht *= 2;
-        lc.ht = ht;
+        if (max_cells <= std::max<int64_t>(2048, 8 * (int64_t)lc.nmax) && max_cells <= 16384) {
+            lc.use_grid = 1;
+            lc.ccap = (int)((max_cells + 63) & ~63ll);
+        } else {
+            lc.use_grid = 0;
+            int ht = 64;
+            while (ht < lc.nmax + lc.nmax / 2) ht *= 2;
+            lc.ccap = ht;
+        }
         size_t lcap = std::max<size_t>({(size_t)lc.nmax, (size_t)(s.list_factor * lc.nmax), s.list_min});
         lcap = std::min<size_t>(lcap, kMaxListEntries);
         lcap = (lcap + 7) & ~(size_t)7;
         lc.lcap = (int)lcap;
-        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ht, lc.lcap);
-        if (lc.lds > kLdsLimit)
+        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0);
+        if (lc.lds > h->lds_limit)
             return fail(h, EGG_ERR_UNSUPPORTED,
                         "a tile of %d particles with %d visit-list entries needs %zu bytes of LDS (limit %zu)",
-                        lc.nmax, lc.lcap, lc.lds, kLdsLimit);
+                        lc.nmax, lc.lcap, lc.lds, h->lds_limit);
         s.classes.push_back(lc);
         t0 = t1;
     }
@@ -623,10 +634,12 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.n_collision_steps = C;
         A.nmax = lc.nmax;
         A.amax = lc.amax;
-        A.ht = lc.ht;
+        A.ccap = lc.ccap;
+        A.use_grid = lc.use_grid;
         A.lcap = lc.lcap;
         A.status = s.d_status;
-        hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3(EGG_WAVE), lc.lds, s.stream, A);
+        hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax)), lc.lds,
+                           s.stream, A);
         HIP_TRY(h, hipGetLastError());
         h->stats.kernel_launches++;
     }
@@ -833,11 +846,16 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
     (void)hipGetDeviceProperties(&h->prop, device);
     h->sys[0].cfg = *white;
     h->sys[1].cfg = yolk ? *yolk : *white;
-    e = hipFuncSetAttribute((const void *)egg_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
-    if (e != hipSuccess) {
-        delete h;
-        return fail(nullptr, EGG_ERR_DEVICE, "cannot raise the step kernel's LDS limit: %s", hipGetErrorString(e));
+    // a workgroup gets 64 KiB of dynamic LDS by default; ask for as much of the CU's 160 KiB as the
+    // runtime grants for this kernel
+    for (size_t want = kLdsMax; want > h->lds_limit; want -= 16 * 1024) {
+        e = hipFuncSetAttribute((const void *)egg_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess) {
+            h->lds_limit = want;
+            break;
+        }
     }
+    (void)hipGetLastError();
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];
         s.margin = h->opt_margin;

@@ -43,7 +43,7 @@ __device__ unsigned long long egg_prof[16];
         _pt = _n;                                                \
     }
 #define PROF_FLUSH                                                                                    \
-    if (lane == 0 && tile == 0) {                                                                    \
+    if (tid == 0 && tile == 0 && n > 64) {                                                          \
         for (int _k = 0; _k < 10; ++_k) atomicAdd(&egg_prof[_k], _pacc[_k]);                           \
         atomicAdd(&egg_prof[10], rounds_total);                                                      \
         atomicAdd(&egg_prof[11], 1ull);                                                              \
@@ -56,37 +56,42 @@ __device__ unsigned long long egg_prof[16];
 
 namespace {
 
+// LDS image of one tile.  Double-buffered arrays ("this pass" / "previous un-cleared pass") are
+// addressed by arithmetic, never through pointer tables, so that a runtime buffer index does not
+// force the struct into scratch memory.
 struct Tile {
-    // particle state
-    double *x, *y, *px, *py, *vx, *vy, *w, *r;
+    double2 *pos;   // [n] (x, y)
+    double2 *wr;    // [n] (inverse mass, radius)
+    double2 *prev;  // [n] position at the start of the sub-step
+    double2 *vel;   // [n]
     double *atx, *aty, *afd;
-    uint32_t *ckey_b;                 // [2][nmax]      packed tile-relative cell of each particle
-    uint32_t *hkeys_b, *hmeta_b;      // [2][ht]        cell hash: key, (start << 16 | count)
-    uint32_t *own_off_b;              // [2][nmax + 1]  CSR offsets of the visit lists
-    uint32_t *inc_off, *fill;
-    uint32_t *queue_b;                // [2][nmax / 2 + 1]
-    int s_n, s_h, s_o, s_q, s_l;      // strides of the double-buffered arrays
-    // double-buffered arrays are addressed by arithmetic, never through pointer tables, so
-    // that a runtime buffer index does not force the struct into scratch memory
+    uint32_t *ckey_b;     // [2][nmax]     packed tile-relative cell of each particle
+    uint32_t *cell_b;     // [2][ccap]     per cell (start << 16 | count); dense grid or hash slots
+    uint32_t *hkeys_b;    // [2][ccap]     hash mode only: cell key of each slot
+    uint32_t *own_off_b;  // [2][nmax + 1] CSR offsets of the visit lists
+    uint32_t *inc_off;    // [nmax + 1]    CSR offsets of the incoming lists (transposition)
+    uint32_t *fill;       // [nmax]        scratch counters
+    uint32_t *done;       // [nmax]        pairs finished so far per particle (the dataflow counters)
+    uint32_t *own_pack;   // [lcap]        visit lists as (other | rank of the pair in other's sequence << 16)
+    uint32_t *inc_tmp;    // [lcap]        scratch: incoming (self | visit-list position << 16)
+    int32_t *aclaim, *aoff, *abatch;
+    int32_t *sc;  // scalars: 2 particle count; 3 origin x; 4 origin y; 5 misc; 6 gw; 7 gh; 8.. scan carries
+    uint16_t *hitems_b;   // [2][nmax]     particles sorted by cell, ascending index inside a cell
+    uint16_t *pslot, *aslot, *nlo;
+    uint16_t *own_ent_b;  // [nbuf][lcap]  visit lists (plain); the previous pass's copy only in exact-budget mode
+    int s_n, s_c, s_o, s_l;
+    int n, na, ccap, lcap, use_grid, gw, ncell;
     __device__ uint32_t *ckey(int b) const { return ckey_b + b * s_n; }
-    __device__ uint32_t *hkeys(int b) const { return hkeys_b + b * s_h; }
-    __device__ uint32_t *hmeta(int b) const { return hmeta_b + b * s_h; }
+    __device__ uint32_t *cell(int b) const { return cell_b + b * s_c; }
+    __device__ uint32_t *hkeys(int b) const { return hkeys_b + b * s_c; }
     __device__ uint32_t *own_off(int b) const { return own_off_b + b * s_o; }
-    __device__ uint32_t *queue(int b) const { return queue_b + b * s_q; }
     __device__ uint16_t *hitems(int b) const { return hitems_b + b * s_n; }
     __device__ uint16_t *own_ent(int b) const { return own_ent_b + b * s_l; }
-    int32_t *aclaim, *aaabb, *aoff, *abatch;
-    int32_t *sc;  // scalars: 0,1 queue counts; 2 total; 3 origin x; 4 origin y; 5 misc
-    uint16_t *hitems_b;               // [2][nmax]      particles sorted by cell
-    uint16_t *pslot, *aslot, *ptr, *nlo, *nxt, *stamp;
-    uint16_t *own_ent_b;              // [2][lcap]      visit lists
-    uint16_t *inc_ent, *inc_tmp;
-    int n, na, ht, lcap;
 };
 
 __device__ inline unsigned char *carve(unsigned char *&p, size_t bytes) {
     unsigned char *q = p;
-    p += (bytes + 7) & ~(size_t)7;
+    p += (bytes + 15) & ~(size_t)15;
     return q;
 }
 
@@ -99,18 +104,19 @@ __device__ inline int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-// exclusive prefix sum of cnt[0..n) into off[0..n], off[n] = total; one wave
-__device__ inline int block_exclusive_scan(const uint32_t *cnt, uint32_t *off, int n, int lane) {
+// exclusive prefix sum of cnt[0..n) into off[0..n], off[n] = total.  Executed by wave 0 of the
+// workgroup only (the arrays are a few hundred entries); callers put barriers around it.
+__device__ inline void wave0_exclusive_scan(const uint32_t *cnt, uint32_t *off, int n, int tid) {
+    if (tid >= 64) return;
     int carry = 0;
     for (int base = 0; base < n; base += 64) {
-        int i = base + lane;
+        int i = base + tid;
         int v = (i < n) ? (int)cnt[i] : 0;
-        int incl = wave_incl_scan(v, lane);
+        int incl = wave_incl_scan(v, tid);
         if (i < n) off[i] = (uint32_t)(carry + incl - v);
         carry += __shfl(incl, 63, 64);
     }
-    if (lane == 0) off[n] = (uint32_t)carry;
-    return carry;
+    if (tid == 0) off[n] = (uint32_t)carry;
 }
 
 __device__ inline int cell_slot(uint32_t ka, uint32_t kb) {
@@ -121,39 +127,43 @@ __device__ inline int cell_slot(uint32_t ka, uint32_t kb) {
     return (dcx + 1) * 3 + (dcy + 1);
 }
 
-__device__ inline uint32_t hash_cell(uint32_t key, int ht) { return (key * 2654435761u) >> 7 & (uint32_t)(ht - 1); }
+__device__ inline uint32_t hash_cell(uint32_t key, int cap) { return (key * 2654435761u) >> 7 & (uint32_t)(cap - 1); }
 
-// returns (start << 16 | count) of the cell's item list, or 0 when the cell is empty
-__device__ inline uint32_t hash_lookup(const uint32_t *keys, const uint32_t *meta, uint32_t key, int ht) {
-    uint32_t h = hash_cell(key, ht);
-    for (int probe = 0; probe < ht; ++probe) {
+// (start << 16 | count) of a cell's item list; 0 when the cell is empty
+__device__ inline uint32_t cell_meta(const Tile &t, int buf, uint32_t key) {
+    if (t.use_grid) return t.cell(buf)[(int)(key & 0xFFFFu) * t.gw + (int)(key >> 16)];
+    const uint32_t *keys = t.hkeys(buf);
+    uint32_t h = hash_cell(key, t.ccap);
+    for (int probe = 0; probe < t.ccap; ++probe) {
         uint32_t k = keys[h];
-        if (k == key) return meta[h];
+        if (k == key) return t.cell(buf)[h];
         if (k == EGG_EMPTY_KEY) return 0;
-        h = (h + 1) & (uint32_t)(ht - 1);
+        h = (h + 1) & (uint32_t)(t.ccap - 1);
     }
     return 0;
 }
 
-// XPBD distance projection between two particles, L:1514-1545 with the collision
-// caller L:1632-1654 (and the numerically dead cohesion block L:1603-1630).
-__device__ inline void solve_pair(const Tile &t, int a, int b, double overlap, double compliance, double eps) {
-    double wa = t.w[a], wb = t.w[b];
-    if (wa + wb < eps) return;  // L:1601
-    double ra = t.r[a], rb = t.r[b];
-    double ax = t.x[a], ay = t.y[a], bx = t.x[b], by = t.y[b];
-    double dx = bx - ax, dy = by - ay;
+// XPBD distance projection between two particles, L:1514-1545 with the collision caller
+// L:1632-1654 (and the numerically dead cohesion block L:1603-1630).  pa/pb are the current
+// positions, wra/wrb the (inverse mass, radius) records.  Returns true when pa/pb changed.
+__device__ inline bool project_pair(const Tile &t, int a, int b, double2 &pa, double2 &pb, double2 wra, double2 wrb,
+                                    double overlap, double compliance, double eps) {
+    double wa = wra.x, wb = wrb.x;
+    if (wa + wb < eps) return false;  // L:1601
+    bool changed = false;
+    double dx = pb.x - pa.x, dy = pb.y - pa.y;
     double d2 = dx * dx + dy * dy;
-    if (d2 <= 0.0 && t.abatch[t.aslot[a]] == t.abatch[t.aslot[b]]) {
-        // cohesion fires only for coincident same-batch particles (interaction distance 0,
-        // L:1608-1616); its corrections are +0 for self and -0 for other, so the only
-        // observable effect is x_self + 0.0 (turns -0.0 into +0.0)
-        ax = ax + 0.0;
-        ay = ay + 0.0;
-        t.x[a] = ax;
-        t.y[a] = ay;
+    if (d2 <= 0.0) {
+        if (t.abatch[t.aslot[a]] == t.abatch[t.aslot[b]]) {
+            // cohesion fires only for coincident same-batch particles (interaction distance 0,
+            // L:1608-1616); its corrections are +0 for self and -0 for other, so the only
+            // observable effect is x_self + 0.0 (turns -0.0 into +0.0)
+            pa.x = pa.x + 0.0;
+            pa.y = pa.y + 0.0;
+            changed = true;
+        }
     }
-    double min_distance = overlap * (ra + rb);
+    double min_distance = overlap * (wra.y + wrb.y);
     if (d2 <= min_distance * min_distance) {
         double current = sqrt(d2);
         double nx, ny;
@@ -179,89 +189,54 @@ __device__ inline void solve_pair(const Tile &t, int a, int b, double overlap, d
             cbx = nx * correction * wb;
             cby = ny * correction * wb;
         }
-        t.x[a] = ax + cax;
-        t.y[a] = ay + cay;
-        t.x[b] = bx + cbx;
-        t.y[b] = by + cby;
+        pa.x = pa.x + cax;
+        pa.y = pa.y + cay;
+        pb.x = pb.x + cbx;
+        pb.y = pb.y + cby;
+        changed = true;
     }
-}
-
-// k-th element of particle i's pair sequence: pairs where i is `other` visited by
-// smaller selves, then i's own visits, then pairs visited by larger selves (stale pass only)
-__device__ inline uint32_t seq_entry(const Tile &t, int cur, int i, int k) {
-    int nl = t.nlo[i];
-    int o0 = (int)t.own_off(cur)[i], no = (int)t.own_off(cur)[i + 1] - o0;
-    int i0 = (int)t.inc_off[i], ni = (int)t.inc_off[i + 1] - i0;
-    if (k < nl) return t.inc_ent[i0 + k];
-    if (k < nl + no) return (uint32_t)t.own_ent(cur)[o0 + k - nl] | EGG_SELF;
-    if (k < no + ni) return t.inc_ent[i0 + k - no];
-    return EGG_NONE;
+    return changed;
 }
 
 struct PassCtx {
-    int cur;          // which own_off/own_ent/ckey/hash buffer is "this pass"
-    int stale;        // previous pass's hash lists and collided set are still alive (Q3)
-    int prev_uncut;   // previous pass visited every adjacent pair (no budget cut)
+    int cur;         // which buffer is "this pass"
+    int stale;       // previous pass's hash lists and collided set are still alive (Q3)
+    int prev_uncut;  // previous pass visited every adjacent pair (no budget cut)
 };
 
-// is the unordered pair {i, j} in `collided` from the previous pass?
-__device__ inline bool in_prev(const Tile &t, const PassCtx &c, int i, int j) {
-    int lo = i < j ? i : j, hi = i < j ? j : i;
-    const uint32_t *ko = t.ckey(c.cur ^ 1);
-    if (cell_slot(ko[hi], ko[lo]) < 0) return false;  // never met in the previous (fresh) pass
-    if (c.prev_uncut) return true;
-    const uint32_t *off = t.own_off(c.cur ^ 1);
-    const uint16_t *ent = t.own_ent(c.cur ^ 1);
-    for (uint32_t e = off[lo]; e < off[lo + 1]; ++e)
-        if (ent[e] == (uint16_t)hi) return true;
-    return false;
-}
+// ------------------------------------------------------------------ visit lists
+//
+// own(i): the partners particle i visits as `self`, in the reference's attempt order.
 
-// does self i visit j when it meets it at 3x3 slot s through j's old (isnew=0) or new cell?
-__device__ inline bool accept(const Tile &t, const PassCtx &c, int i, int j, int s, int isnew) {
-    if (j == i) return false;
-    if (!c.stale) return j > i;  // fresh pass: adjacency is symmetric, the smaller index visits
-    const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.cur ^ 1);
-    uint32_t ki = kn[i];
-    // j can sit in i's attempt order twice (old cell and new cell): first occurrence wins
-    if (!isnew) {
-        int s2 = cell_slot(kn[j], ki);
-        if (s2 >= 0 && s2 < s) return false;
-    } else {
-        int s2 = cell_slot(ko[j], ki);
-        if (s2 >= 0 && s2 <= s) return false;
-    }
-    if (in_prev(t, c, i, j)) return false;
-    if (j < i) {  // j's loop ran first: did it meet i?
-        uint32_t kj = kn[j];
-        if (cell_slot(ki, kj) >= 0 || cell_slot(ko[i], kj) >= 0) return false;
-    }
-    return true;
-}
-
+// fresh pass (hash and collided were cleared): adjacency is symmetric, the smaller index visits,
+// so own(i) = { j > i in the 3x3 cells }, cells in loop order, ascending j inside a cell.
 template <bool FILL>
-__device__ inline int enumerate_visits(const Tile &t, const PassCtx &c, int i, uint16_t *dst) {
-    const uint32_t ki = t.ckey(c.cur)[i];
-    int count = 0;
+__device__ inline int enum_fresh(const Tile &t, int cur, int i, uint16_t *dst) {
+    const uint32_t ki = t.ckey(cur)[i];
+    const uint16_t *items = t.hitems(cur);
+    uint32_t m[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) m[s] = cell_meta(t, cur, (uint32_t)((int)ki + (s / 3 - 1) * 65536 + (s % 3 - 1)));
+    uint16_t it[9][4];
+#pragma unroll
     for (int s = 0; s < 9; ++s) {
-        int dx = s / 3 - 1, dy = s % 3 - 1;
-        uint32_t nk = (uint32_t)((int)ki + dx * 65536 + dy);
-        if (c.stale) {
-            uint32_t m = hash_lookup(t.hkeys(c.cur ^ 1), t.hmeta(c.cur ^ 1), nk, t.ht);
-            int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
-            for (int e = 0; e < cn; ++e) {
-                int j = t.hitems(c.cur ^ 1)[st + e];
-                if (accept(t, c, i, j, s, 0)) {
-                    if (FILL) dst[count] = (uint16_t)j;
-                    ++count;
-                }
+        const int st = (int)(m[s] >> 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) it[s][q] = items[min(st + q, t.n - 1)];  // unconditional; masked by q < cn below
+    }
+    int count = 0;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int st = (int)(m[s] >> 16), cn = (int)(m[s] & 0xFFFFu);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < cn && (int)it[s][q] > i) {
+                if (FILL) dst[count] = it[s][q];
+                ++count;
             }
-        }
-        uint32_t m = hash_lookup(t.hkeys(c.cur), t.hmeta(c.cur), nk, t.ht);
-        int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
-        for (int e = 0; e < cn; ++e) {
-            int j = t.hitems(c.cur)[st + e];
-            if (accept(t, c, i, j, s, 1)) {
+        for (int e = 4; e < cn; ++e) {
+            int j = items[st + e];
+            if (j > i) {
                 if (FILL) dst[count] = (uint16_t)j;
                 ++count;
             }
@@ -270,11 +245,149 @@ __device__ inline int enumerate_visits(const Tile &t, const PassCtx &c, int i, u
     return count;
 }
 
+// is the unordered pair {i, j} in `collided` from the previous pass?  (ko* = previous cells)
+__device__ inline bool in_prev(const Tile &t, const PassCtx &c, int i, int j, uint32_t koi, uint32_t koj) {
+    if (cell_slot(koj, koi) < 0) return false;  // never met in the previous (fresh) pass
+    if (c.prev_uncut) return true;
+    int lo = i < j ? i : j, hi = i < j ? j : i;
+    const uint32_t *off = t.own_off(c.cur ^ 1);
+    const uint16_t *ent = t.own_ent(c.cur ^ 1);
+    for (uint32_t e = off[lo]; e < off[lo + 1]; ++e)
+        if (ent[e] == (uint16_t)hi) return true;
+    return false;
+}
+
+// stale pass: does self i visit j when it meets it at 3x3 slot s through j's old (isnew = 0) or
+// new cell?  kn* / ko* = this pass's / the previous pass's cell of i and j.
+__device__ inline bool accept_stale(const Tile &t, const PassCtx &c, int i, int j, int s, int isnew, uint32_t kni,
+                                    uint32_t koi, uint32_t knj, uint32_t koj) {
+    if (j == i) return false;
+    // j can sit in i's attempt order twice (old cell and new cell): first occurrence wins
+    if (!isnew) {
+        int s2 = cell_slot(knj, kni);
+        if (s2 >= 0 && s2 < s) return false;
+    } else {
+        int s2 = cell_slot(koj, kni);
+        if (s2 >= 0 && s2 <= s) return false;
+    }
+    if (in_prev(t, c, i, j, koi, koj)) return false;
+    if (j < i) {  // j's loop ran first: did it meet i?
+        if (cell_slot(kni, knj) >= 0 || cell_slot(koi, knj) >= 0) return false;
+    }
+    return true;
+}
+
+template <bool FILL>
+__device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint16_t *dst) {
+    const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.cur ^ 1);
+    const uint32_t kni = kn[i], koi = ko[i];
+    int count = 0;
+    for (int s = 0; s < 9; ++s) {
+        const uint32_t nk = (uint32_t)((int)kni + (s / 3 - 1) * 65536 + (s % 3 - 1));
+        const uint32_t mo = cell_meta(t, c.cur ^ 1, nk), mn = cell_meta(t, c.cur, nk);
+#pragma unroll
+        for (int isnew = 0; isnew < 2; ++isnew) {
+            const uint32_t m = isnew ? mn : mo;
+            const uint16_t *items = t.hitems(isnew ? c.cur : c.cur ^ 1);
+            const int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
+            for (int e0 = 0; e0 < cn; e0 += 4) {
+                int j[4];
+                uint32_t knj[4], koj[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) j[q] = (int)items[min(st + e0 + q, t.n - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    knj[q] = kn[j[q]];
+                    koj[q] = ko[j[q]];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (e0 + q < cn && accept_stale(t, c, i, j[q], s, isnew, kni, koi, knj[q], koj[q])) {
+                        if (FILL) dst[count] = (uint16_t)j[q];
+                        ++count;
+                    }
+            }
+        }
+    }
+    return count;
+}
+
+// -------------------------------------------------------------- pair scheduling
+//
+// Every particle has an ordered sequence of pairs: pairs where it is `other`, visited by smaller
+// selves (ascending), then its own visits, then pairs visited by larger selves (stale pass only).
+// A pair may run when it is the next pending pair of BOTH particles; running every pair under
+// that rule reproduces the sequential loop bit for bit.
+//
+// t.done[p] counts the finished pairs of particle p.  The k-th own pair (a -> b) of a is ready when
+// done[a] == nlo[a] + k and done[b] == rank of that pair in b's sequence (precomputed, own_pack).
+// The thread of `self` runs the projection, stores both positions, THEN both counters.  A reader
+// loads the counters THEN the positions.  One wave's LDS operations execute in issue order, so a
+// reader that sees the new counter also sees the new position; no barrier is needed and waves
+// of the workgroup run ahead of each other freely.
+#define EGG_COMPILER_BARRIER() __asm__ volatile("" ::: "memory")
+
+__device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, int nthreads, double overlap,
+                                       double compliance, double eps, int total, unsigned int &spins_out) {
+    volatile uint32_t *done = t.done;
+    int solved = 0;
+    unsigned int spins = 0;
+    // A thread walks its particles in ascending order (one particle when n <= nthreads).  That
+    // cannot deadlock: the reference's sequential order, pairs sorted by (self index, position), is
+    // a topological order of the dependencies, so a pair only ever waits for pairs of selves <= its
+    // own self, and those belong to the same or an earlier slice [base * nthreads, ...) which
+    // every thread finishes first.
+    const int per = (n + nthreads - 1) / nthreads;
+    const unsigned int cap = 16u * (unsigned int)(total + 8) + 4096u;
+    for (int base = 0; base < per; ++base) {
+        const int a = tid + base * nthreads;
+        const bool has = a < n;
+        const int as = has ? a : 0;
+        const int o0 = has ? (int)t.own_off(cur)[a] : 0;
+        const int no = has ? (int)t.own_off(cur)[a + 1] - o0 : 0;
+        const uint32_t nl = t.nlo[as];
+        const double2 wra = t.wr[as];
+        int k = 0;
+        uint32_t ent = t.own_pack[min(o0, t.lcap - 1)];
+        while (__any(k < no)) {
+            const bool live = k < no;
+            const int b = live ? (int)(ent & 0xFFFFu) : 0;
+            const uint32_t rb = ent >> 16;
+            const uint32_t da = done[as];
+            const uint32_t db = done[b];
+            EGG_COMPILER_BARRIER();  // counters first, then the data they guard
+            double2 pa = t.pos[as];
+            double2 pb = t.pos[b];
+            const double2 wrb = t.wr[b];
+            const uint32_t ent_next = t.own_pack[min(o0 + k + 1, t.lcap - 1)];
+            const bool ready = live && da == nl + (uint32_t)k && db == rb;
+            if (ready) {
+                if (project_pair(t, a, b, pa, pb, wra, wrb, overlap, compliance, eps)) {
+                    t.pos[a] = pa;
+                    t.pos[b] = pb;
+                }
+                EGG_COMPILER_BARRIER();  // data first, then the counters that publish it
+                done[a] = da + 1;
+                done[b] = db + 1;
+                ++k;
+                ent = ent_next;
+                ++solved;
+            }
+            if (!__any(ready)) __builtin_amdgcn_s_sleep(1);
+            if (++spins > cap) break;  // cannot happen; guards against a hang
+        }
+    }
+    spins_out = spins;
+    return solved;
+}
+
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepArgs A) {
+extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel(EggStepArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const int lane = tid & 63;
     const int tile = blockIdx.x;
     if (tile >= A.n_tiles) return;
     PROF_DECL
@@ -283,54 +396,46 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
     Tile t;
     {
         unsigned char *p = smem;
-        size_t n = (size_t)A.nmax, a = (size_t)A.amax, h = (size_t)A.ht, l = (size_t)A.lcap;
-        t.x = (double *)carve(p, n * 8);
-        t.y = (double *)carve(p, n * 8);
-        t.px = (double *)carve(p, n * 8);
-        t.py = (double *)carve(p, n * 8);
-        t.vx = (double *)carve(p, n * 8);
-        t.vy = (double *)carve(p, n * 8);
-        t.w = (double *)carve(p, n * 8);
-        t.r = (double *)carve(p, n * 8);
+        size_t n = (size_t)A.nmax, a = (size_t)A.amax, cc = (size_t)A.ccap, l = (size_t)A.lcap;
+        t.pos = (double2 *)carve(p, n * 16);
+        t.wr = (double2 *)carve(p, n * 16);
+        t.prev = (double2 *)carve(p, n * 16);
+        t.vel = (double2 *)carve(p, n * 16);
         t.atx = (double *)carve(p, a * 8);
         t.aty = (double *)carve(p, a * 8);
         t.afd = (double *)carve(p, a * 8);
         t.ckey_b = (uint32_t *)carve(p, 2 * n * 4);
-        t.hkeys_b = (uint32_t *)carve(p, 2 * h * 4);
-        t.hmeta_b = (uint32_t *)carve(p, 2 * h * 4);
+        t.cell_b = (uint32_t *)carve(p, 2 * cc * 4);
+        t.hkeys_b = (uint32_t *)carve(p, A.use_grid ? 0 : 2 * cc * 4);
         t.own_off_b = (uint32_t *)carve(p, 2 * (n + 1) * 4);
         t.inc_off = (uint32_t *)carve(p, (n + 1) * 4);
         t.fill = (uint32_t *)carve(p, n * 4);
-        t.queue_b = (uint32_t *)carve(p, (n / 2 + 1) * 2 * 4);
-        t.s_n = (int)n;
-        t.s_h = (int)h;
-        t.s_o = (int)n + 1;
-        t.s_q = (int)n / 2 + 1;
-        t.s_l = (int)l;
+        t.done = (uint32_t *)carve(p, n * 4);
+        t.own_pack = (uint32_t *)carve(p, l * 4);
+        t.inc_tmp = (uint32_t *)carve(p, l * 4);
         t.aclaim = (int32_t *)carve(p, a * 4 * 4);
-        t.aaabb = (int32_t *)carve(p, a * 4 * 4);
         t.aoff = (int32_t *)carve(p, (a + 1) * 4);
         t.abatch = (int32_t *)carve(p, a * 4);
         t.sc = (int32_t *)carve(p, 16 * 4);
         t.hitems_b = (uint16_t *)carve(p, 2 * n * 2);
         t.pslot = (uint16_t *)carve(p, n * 2);
         t.aslot = (uint16_t *)carve(p, n * 2);
-        t.ptr = (uint16_t *)carve(p, n * 2);
         t.nlo = (uint16_t *)carve(p, n * 2);
-        t.nxt = (uint16_t *)carve(p, n * 2);
-        t.stamp = (uint16_t *)carve(p, n * 2);
-        t.own_ent_b = (uint16_t *)carve(p, 2 * l * 2);
-        t.inc_ent = (uint16_t *)carve(p, l * 2);
-        t.inc_tmp = (uint16_t *)carve(p, l * 2);
-        t.ht = A.ht;
+        t.own_ent_b = (uint16_t *)carve(p, (A.single_tile ? 2 : 1) * l * 2);
+        t.s_n = (int)n;
+        t.s_c = (int)cc;
+        t.s_o = (int)n + 1;
+        t.s_l = A.single_tile ? (int)l : 0;  // without exact-budget mode the previous lists are never read
+        t.ccap = A.ccap;
         t.lcap = A.lcap;
+        t.use_grid = A.use_grid;
     }
 
     // -------------------------------------------------------------- load tile
     const int a_begin = A.tile_atom_begin[tile];
     const int na = A.tile_atom_begin[tile + 1] - a_begin;
     t.na = na;
-    if (lane == 0) {
+    if (tid == 0) {
         int off = 0;
         int ox = 0x7FFFFFFF, oy = 0x7FFFFFFF, hx = -0x7FFFFFFF, hy = -0x7FFFFFFF;
         for (int k = 0; k < na; ++k) {
@@ -342,10 +447,6 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
             oy = min(oy, t.aclaim[4 * k + 1]);
             hx = max(hx, t.aclaim[4 * k + 2]);
             hy = max(hy, t.aclaim[4 * k + 3]);
-            t.aaabb[4 * k + 0] = 0x7FFFFFFF;
-            t.aaabb[4 * k + 1] = 0x7FFFFFFF;
-            t.aaabb[4 * k + 2] = -0x7FFFFFFF;
-            t.aaabb[4 * k + 3] = -0x7FFFFFFF;
             t.atx[k] = A.atom_tx[atom];
             t.aty[k] = A.atom_ty[atom];
             t.afd[k] = A.atom_fd[atom];
@@ -353,33 +454,35 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
         }
         t.aoff[na] = off;
         t.sc[2] = off;
-        t.sc[3] = ox - 2;  // packed cell coordinates are relative to this origin and stay >= 1
+        // packed cell coordinates are relative to (ox - 2, oy - 2): claimed cells map to
+        // [2, ext + 2], their 3x3 neighbours to [1, ext + 3], so a grid of ext + 4 covers them
+        t.sc[3] = ox - 2;
         t.sc[4] = oy - 2;
-        // 3x3 lookups reach one cell beyond the claim box on both sides
-        if ((long long)hx - (ox - 2) + 2 > 65534ll || (long long)hy - (oy - 2) + 2 > 65534ll) {
-            atomicExch(&A.status->fail_range, 1);
-        }
+        long long gw = (long long)hx - ox + 4, gh = (long long)hy - oy + 4;
+        t.sc[6] = (int)min(gw, 65535ll);
+        t.sc[7] = (int)min(gh, 65535ll);
+        if (gw > 65534ll || gh > 65534ll) atomicExch(&A.status->fail_range, 1);
+        if (A.use_grid && gw * gh > (long long)A.ccap) atomicExch(&A.status->fail_overflow, 1);
         if (off > A.nmax || na > A.amax) atomicExch(&A.status->fail_overflow, 1);
     }
     __syncthreads();
     const int n = min(t.sc[2], A.nmax);
     t.n = n;
     const int org_x = t.sc[3], org_y = t.sc[4];
+    t.gw = t.sc[6];
+    t.ncell = A.use_grid ? (int)min((long long)t.sc[6] * t.sc[7], (long long)A.ccap) : A.ccap;
 
     for (int k = 0; k < na; ++k) {
         int atom = A.tile_atoms[a_begin + k];
         int g0 = A.atom_offset[atom];
         int l0 = t.aoff[k], cnt = t.aoff[k + 1] - l0;
-        for (int q = lane; q < cnt; q += EGG_WAVE) {
+        for (int q = tid; q < cnt; q += nthreads) {
             int i = l0 + q;
             if (i >= n) break;
             int g = g0 + q;
-            t.x[i] = A.x_in[g];
-            t.y[i] = A.y_in[g];
-            t.vx[i] = A.vx_in[g];
-            t.vy[i] = A.vy_in[g];
-            t.w[i] = A.inv_mass[g];
-            t.r[i] = A.radius[g];
+            t.pos[i] = make_double2(A.x_in[g], A.y_in[g]);
+            t.vel[i] = make_double2(A.vx_in[g], A.vy_in[g]);
+            t.wr[i] = make_double2(A.inv_mass[g], A.radius[g]);
             t.aslot[i] = (uint16_t)k;
         }
     }
@@ -392,32 +495,30 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
     if (budget_m < 1) budget_m = 1;
 
     int cur = 0;
-    int have_prev = 0;   // buffers cur^1 hold an un-cleared previous pass
+    int have_prev = 0;  // buffers cur^1 hold an un-cleared previous pass
     int prev_uncut = 1;
     int pass_seq = 0;
-    unsigned long long rounds_total = 0;
+    unsigned long long spins_total = 0;
     unsigned int max_list = 0;
     bool bad = false;
 
     for (int s = 0; s < A.n_substeps; ++s) {
-        // ------------------------------------------------ pre-solve, L:1393-1432
-        for (int i = lane; i < n; i += EGG_WAVE) {
-            double x = t.x[i], y = t.y[i];
-            t.px[i] = x;
-            t.py[i] = y;
-            double vx = t.vx[i] * A.damping;
-            double vy = t.vy[i] * A.damping;
-            t.vx[i] = vx;
-            t.vy[i] = vy;
-            x = x + sub_delta * vx;
-            y = y + sub_delta * vy;
-            // ------------------------------------- follow constraint, L:1435-1471
+        // ------------------------- pre-solve (L:1393-1432) + follow constraint (L:1435-1471)
+        for (int i = tid; i < n; i += nthreads) {
+            double2 ps = t.pos[i];
+            double2 v = t.vel[i];
+            t.prev[i] = ps;
+            v.x = v.x * A.damping;
+            v.y = v.y * A.damping;
+            t.vel[i] = v;
+            double x = ps.x + sub_delta * v.x;
+            double y = ps.y + sub_delta * v.y;
             int k = t.aslot[i];
             double fx = t.atx[k], fy = t.aty[k];
             double dx = fx - x, dy = fy - y;
             double current = sqrt(dx * dx + dy * dy);
             double target = t.afd[k];
-            double im = t.w[i];
+            double im = t.wr[i].x;
             if (im > eps && current > target) {
                 double nx, ny;
                 if (current < eps) {
@@ -432,8 +533,7 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
                 x = x + nx * lambda * im;
                 y = y + ny * lambda * im;
             }
-            t.x[i] = x;
-            t.y[i] = y;
+            t.pos[i] = make_double2(x, y);
         }
         __syncthreads();
         PROF(1)  // pre-solve + follow
@@ -445,14 +545,18 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
             ctx.prev_uncut = prev_uncut;
 
             // ----------------------------------- rebuild spatial hash, L:1486-1511
-            for (int h = lane; h < t.ht; h += EGG_WAVE) {
-                t.hkeys(cur)[h] = EGG_EMPTY_KEY;
-                t.hmeta(cur)[h] = 0;
+            for (int h = tid; h < t.ncell; h += nthreads) t.cell(cur)[h] = 0;
+            if (!t.use_grid)
+                for (int h = tid; h < t.ncell; h += nthreads) t.hkeys(cur)[h] = EGG_EMPTY_KEY;
+            for (int i = tid; i < n; i += nthreads) {
+                t.fill[i] = 0;
+                t.done[i] = 0;
             }
             __syncthreads();
-            for (int i = lane; i < n; i += EGG_WAVE) {
-                double fcx = floor(t.x[i] / A.cell_size);
-                double fcy = floor(t.y[i] / A.cell_size);
+            for (int i = tid; i < n; i += nthreads) {
+                double2 ps = t.pos[i];
+                double fcx = floor(ps.x / A.cell_size);
+                double fcy = floor(ps.y / A.cell_size);
                 const int32_t *cl = &t.aclaim[4 * t.aslot[i]];
                 // NaN / out-of-range coordinates fail the box test below
                 int cx = (fcx >= -2.0e9 && fcx <= 2.0e9) ? (int)fcx : 0x7FFFFFF0;
@@ -464,66 +568,81 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
                 }
                 uint32_t key = ((uint32_t)(cx - org_x) << 16) | (uint32_t)(cy - org_y);
                 t.ckey(cur)[i] = key;
-                uint32_t h = hash_cell(key, t.ht);
-                for (;;) {
-                    uint32_t old = atomicCAS(&t.hkeys(cur)[h], EGG_EMPTY_KEY, key);
-                    if (old == EGG_EMPTY_KEY || old == key) break;
-                    h = (h + 1) & (uint32_t)(t.ht - 1);
+                uint32_t h;
+                if (t.use_grid) {
+                    h = (uint32_t)((cy - org_y) * t.gw + (cx - org_x));
+                    if (h >= (uint32_t)t.ncell) h = 0;  // only after a range/overflow failure
+                } else {
+                    h = hash_cell(key, t.ccap);
+                    for (;;) {
+                        uint32_t old = atomicCAS(&t.hkeys(cur)[h], EGG_EMPTY_KEY, key);
+                        if (old == EGG_EMPTY_KEY || old == key) break;
+                        h = (h + 1) & (uint32_t)(t.ccap - 1);
+                    }
                 }
                 t.pslot[i] = (uint16_t)h;
-                atomicAdd(&t.hmeta(cur)[h], 1u);
+                atomicAdd(&t.cell(cur)[h], 1u);
             }
-            __syncthreads();
-            {   // cell start offsets: exclusive scan of the per-slot counts
+            if (__syncthreads_or(bad)) {
+                // a particle left its claim: this step will be discarded and re-run with new tiles,
+                // so stop here (the pair scheduler must not run on inconsistent cells)
+                if (tid == 0) atomicExch(&A.status->fail_claim, 1);
+                return;
+            }
+            if (tid < 64) {  // cell start offsets: exclusive scan of the per-cell counts (wave 0)
                 int carry = 0;
-                for (int base = 0; base < t.ht; base += EGG_WAVE) {
+                for (int base = 0; base < t.ncell; base += 64) {
                     int h = base + lane;
-                    int v = (int)t.hmeta(cur)[h];
+                    int v = (h < t.ncell) ? (int)t.cell(cur)[h] : 0;
                     int incl = wave_incl_scan(v, lane);
-                    t.hmeta(cur)[h] = ((uint32_t)(carry + incl - v) << 16) | (uint32_t)v;
+                    if (h < t.ncell) t.cell(cur)[h] = ((uint32_t)(carry + incl - v) << 16) | (uint32_t)v;
                     carry += __shfl(incl, 63, 64);
                 }
             }
-            for (int i = lane; i < n; i += EGG_WAVE) t.fill[i] = 0;
             __syncthreads();
             // unordered scatter, then rank inside the cell so that each cell's items ascend (L:1509)
-            for (int i = lane; i < n; i += EGG_WAVE) {
-                uint32_t m = t.hmeta(cur)[t.pslot[i]];
+            for (int i = tid; i < n; i += nthreads) {
+                uint32_t m = t.cell(cur)[t.pslot[i]];
                 uint32_t pos = atomicAdd(&t.fill[m >> 16], 1u);
-                t.inc_tmp[(m >> 16) + pos] = (uint16_t)i;
+                t.inc_tmp[(m >> 16) + pos] = (uint32_t)i;
             }
             __syncthreads();
-            for (int i = lane; i < n; i += EGG_WAVE) {
-                uint32_t m = t.hmeta(cur)[t.pslot[i]];
+            for (int i = tid; i < n; i += nthreads) {
+                uint32_t m = t.cell(cur)[t.pslot[i]];
                 int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
                 int rank = 0;
-                for (int e = 0; e < cn; ++e) rank += (t.inc_tmp[st + e] < (uint16_t)i) ? 1 : 0;
+                for (int e = 0; e < cn; ++e) rank += (t.inc_tmp[st + e] < (uint32_t)i) ? 1 : 0;
                 t.hitems(cur)[st + rank] = (uint16_t)i;
             }
             __syncthreads();
             PROF(2)  // cell hash
 
             // ---------------------------------------- visit lists (count, scan, fill)
-            for (int i = lane; i < n; i += EGG_WAVE)
-                t.fill[i] = (uint32_t)enumerate_visits<false>(t, ctx, i, nullptr);
+            if (ctx.stale) {
+                for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_stale<false>(t, ctx, i, nullptr);
+            } else {
+                for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_fresh<false>(t, cur, i, nullptr);
+            }
             __syncthreads();
             PROF(3)  // visit count
-            int total = block_exclusive_scan(t.fill, t.own_off(cur), n, lane);
+            wave0_exclusive_scan(t.fill, t.own_off(cur), n, tid);
             __syncthreads();
+            int total = (int)t.own_off(cur)[n];
             max_list = max(max_list, (unsigned int)total);  // what this pass needs, even when it does not fit
             if (total > t.lcap) {
-                if (lane == 0) atomicExch(&A.status->fail_overflow, 1);
-                bad = true;
-                // truncate so that nothing below indexes out of bounds; results are discarded
-                for (int i = lane; i <= n; i += EGG_WAVE) t.own_off(cur)[i] = min(t.own_off(cur)[i], (uint32_t)t.lcap);
-                __syncthreads();
-            }
-            if (total <= t.lcap) {
-                for (int i = lane; i < n; i += EGG_WAVE)
-                    enumerate_visits<true>(t, ctx, i, &t.own_ent(cur)[t.own_off(cur)[i]]);
+                // the launch has too little list room: report what is needed and stop; the host
+                // re-runs the step with larger lists
+                if (tid == 0) {
+                    atomicExch(&A.status->fail_overflow, 1);
+                    atomicMax(&A.status->max_list, (unsigned long long)total);
+                }
+                return;
+            } else if (ctx.stale) {
+                for (int i = tid; i < n; i += nthreads)
+                    enum_stale<true>(t, ctx, i, &t.own_ent(cur)[t.own_off(cur)[i]]);
             } else {
-                for (int e = lane; e < t.lcap; e += EGG_WAVE) t.own_ent(cur)[e] = 0;
-                total = t.lcap;
+                for (int i = tid; i < n; i += nthreads)
+                    enum_fresh<true>(t, cur, i, &t.own_ent(cur)[t.own_off(cur)[i]]);
             }
             __syncthreads();
 
@@ -532,20 +651,22 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
             int this_cut = 0;
             if (A.single_tile) {
                 // pairs failing the mass guard (L:1601) are marked but not counted; count them out
-                long long counted = 0;
                 long long cut_pos = -1;
-                // (serial in lane 0 only when such pairs can exist; otherwise position = count)
+                // (serial in thread 0 only when such pairs can exist; otherwise position = count)
                 bool guard_possible = false;
-                for (int i = lane; i < n; i += EGG_WAVE) guard_possible |= (t.w[i] * 2.0 < eps) || !(t.w[i] == t.w[i]);
-                guard_possible = __any(guard_possible);
+                for (int i = tid; i < n; i += nthreads) {
+                    double w = t.wr[i].x;
+                    guard_possible |= (w * 2.0 < eps) || !(w == w);
+                }
+                guard_possible = __syncthreads_or(guard_possible);
                 if (!guard_possible) {
                     if ((long long)total > budget_m) cut_pos = budget_m;  // keep entries [0, budget_m)
                 } else {
-                    if (lane == 0) {
-                        long long cp = -1;
+                    if (tid == 0) {
+                        long long cp = -1, counted = 0;
                         for (int i = 0; i < n && cp < 0; ++i)
                             for (uint32_t e = t.own_off(cur)[i]; e < t.own_off(cur)[i + 1]; ++e) {
-                                if (t.w[i] + t.w[t.own_ent(cur)[e]] < eps) continue;
+                                if (t.wr[i].x + t.wr[t.own_ent(cur)[e]].x < eps) continue;
                                 if (++counted >= budget_m) {
                                     cp = (long long)e + 1;
                                     break;
@@ -558,128 +679,76 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
                 }
                 if (cut_pos >= 0 && cut_pos < total) {
                     this_cut = 1;
-                    for (int i = lane; i <= n; i += EGG_WAVE)
+                    __syncthreads();
+                    for (int i = tid; i <= n; i += nthreads)
                         t.own_off(cur)[i] = min(t.own_off(cur)[i], (uint32_t)cut_pos);
                     total = (int)cut_pos;
                     __syncthreads();
                 }
             }
-            if (lane == 0) {
+            if (tid == 0) {
                 atomicAdd(&A.status->visits[min(pass_seq, EGG_MAX_PASSES - 1)], (unsigned long long)total);
                 if (this_cut) atomicExch(&A.status->was_cut, 1);
             }
 
             PROF(5)  // budget
-            // ---------------- incoming lists: transpose of the visit lists, ascending in self
-            for (int i = lane; i < n; i += EGG_WAVE) t.fill[i] = 0;
+            // ---- ranks: transpose the visit lists (incoming pairs per particle), rank every incoming
+            //      pair inside its particle's sequence, and store the rank next to the visit entry
+            for (int i = tid; i < n; i += nthreads) t.fill[i] = 0;
             __syncthreads();
-            for (int i = lane; i < n; i += EGG_WAVE)
+            for (int i = tid; i < n; i += nthreads)
                 for (uint32_t e = t.own_off(cur)[i]; e < t.own_off(cur)[i + 1]; ++e)
                     atomicAdd(&t.fill[t.own_ent(cur)[e]], 1u);
             __syncthreads();
-            block_exclusive_scan(t.fill, t.inc_off, n, lane);
+            wave0_exclusive_scan(t.fill, t.inc_off, n, tid);
             __syncthreads();
-            for (int i = lane; i < n; i += EGG_WAVE) t.fill[i] = 0;
+            for (int i = tid; i < n; i += nthreads) t.fill[i] = 0;
             __syncthreads();
-            for (int i = lane; i < n; i += EGG_WAVE)
+            for (int i = tid; i < n; i += nthreads)
                 for (uint32_t e = t.own_off(cur)[i]; e < t.own_off(cur)[i + 1]; ++e) {
                     int j = t.own_ent(cur)[e];
                     uint32_t pos = atomicAdd(&t.fill[j], 1u);
-                    t.inc_tmp[t.inc_off[j] + pos] = (uint16_t)i;
+                    t.inc_tmp[t.inc_off[j] + pos] = (uint32_t)i | (e << 16);
                 }
             __syncthreads();
-            for (int i = lane; i < n; i += EGG_WAVE) {
-                int st = (int)t.inc_off[i], cn = (int)t.inc_off[i + 1] - st;
-                int nl = 0;
+            for (int i = tid; i < n; i += nthreads) {
+                const int st = (int)t.inc_off[i], cn = (int)t.inc_off[i + 1] - st;
+                const uint32_t nown = t.own_off(cur)[i + 1] - t.own_off(cur)[i];
+                uint32_t nl = 0;
                 for (int e = 0; e < cn; ++e) {
-                    uint16_t cself = t.inc_tmp[st + e];
-                    int rank = 0;
-                    for (int f = 0; f < cn; ++f) rank += (t.inc_tmp[st + f] < cself) ? 1 : 0;
-                    t.inc_ent[st + rank] = cself;
-                    nl += (cself < (uint16_t)i) ? 1 : 0;
+                    const uint32_t rec = t.inc_tmp[st + e];
+                    const uint32_t cself = rec & 0xFFFFu;
+                    uint32_t rank = 0;
+                    for (int f = 0; f < cn; ++f) rank += ((t.inc_tmp[st + f] & 0xFFFFu) < cself) ? 1u : 0u;
+                    // pairs visited by a larger self come after i's own visits (stale pass only)
+                    if (cself > (uint32_t)i) rank += nown;
+                    else ++nl;
+                    t.own_pack[rec >> 16] = (uint32_t)i | (rank << 16);
                 }
                 t.nlo[i] = (uint16_t)nl;
-                t.ptr[i] = 0;
-                t.stamp[i] = EGG_NONE;
             }
             __syncthreads();
 
             PROF(6)  // transpose
-            // -------------------------------------- DAG execution of the pair solves
-            for (int i = lane; i < n; i += EGG_WAVE) t.nxt[i] = (uint16_t)seq_entry(t, cur, i, 0);
-            if (lane == 0) {
-                t.sc[0] = 0;
-                t.sc[1] = 0;
-            }
+            // -------------------------------------- dataflow execution of the pair projections
+            unsigned int spins = 0;
+            int solved = execute_dataflow(t, cur, n, tid, nthreads, A.overlap_factor, A.collision_compliance, eps,
+                                          total, spins);
+            spins_total += spins;
             __syncthreads();
-            for (int i = lane; i < n; i += EGG_WAVE) {
-                uint32_t e = t.nxt[i];
-                if (e != EGG_NONE && (e & EGG_SELF)) {
-                    int p = (int)(e & EGG_IDX);
-                    if (t.nxt[p] == (uint16_t)i) {
-                        int pos = atomicAdd(&t.sc[0], 1);
-                        t.queue(0)[pos] = (uint32_t)i | ((uint32_t)p << 16);
-                    }
-                }
-            }
-            __syncthreads();
-            int qc = 0;
-            unsigned int round = 0;
-            int done_pairs = 0;
-            for (;;) {
-                const int qn = t.sc[qc];
-                if (qn == 0) break;
-                if (round > (unsigned int)total) break;  // cannot happen; guards against a hang
-                __syncthreads();
-                if (lane == 0) t.sc[qc ^ 1] = 0;
-                for (int base = 0; base < qn; base += EGG_WAVE) {
-                    int q = base + lane;
-                    if (q < qn) {
-                        uint32_t pr = t.queue(qc)[q];
-                        int a = (int)(pr & 0xFFFFu), b = (int)(pr >> 16);
-                        solve_pair(t, a, b, A.overlap_factor, A.collision_compliance, eps);
-                        int pa = t.ptr[a] + 1, pb = t.ptr[b] + 1;
-                        t.ptr[a] = (uint16_t)pa;
-                        t.ptr[b] = (uint16_t)pb;
-                        t.nxt[a] = (uint16_t)seq_entry(t, cur, a, pa);
-                        t.nxt[b] = (uint16_t)seq_entry(t, cur, b, pb);
-                        t.stamp[a] = (uint16_t)round;
-                        t.stamp[b] = (uint16_t)round;
-                    }
-                }
-                done_pairs += qn;
-                __syncthreads();
-                for (int base = 0; base < qn; base += EGG_WAVE) {
-                    int q = base + lane;
-                    if (q < qn) {
-                        uint32_t pr = t.queue(qc)[q];
-#pragma unroll
-                        for (int side = 0; side < 2; ++side) {
-                            int p = side == 0 ? (int)(pr & 0xFFFFu) : (int)(pr >> 16);
-                            uint32_t e = t.nxt[p];
-                            if (e == EGG_NONE) continue;
-                            int o = (int)(e & EGG_IDX);
-                            uint32_t eo = t.nxt[o];
-                            if (eo == EGG_NONE || (int)(eo & EGG_IDX) != p) continue;
-                            bool p_self = (e & EGG_SELF) != 0;
-                            if (t.stamp[o] == (uint16_t)round && !p_self) continue;  // o's lane pushes it
-                            int pos = atomicAdd(&t.sc[qc ^ 1], 1);
-                            t.queue(qc ^ 1)[pos] = p_self ? ((uint32_t)p | ((uint32_t)o << 16))
-                                                          : ((uint32_t)o | ((uint32_t)p << 16));
-                        }
-                    }
-                }
-                __syncthreads();
-                qc ^= 1;
-                ++round;
-            }
-            rounds_total += round;
             PROF(7)  // DAG
-            if (done_pairs != total && !__any(bad)) {
-                // lists of a discarded (bad) step may be inconsistent; otherwise this is a bug
-                if (lane == 0) atomicExch(&A.status->fail_stall, 1);
+            {   // every particle must have finished its whole sequence
+                bool short_ = false;
+                for (int i = tid; i < n; i += nthreads) {
+                    uint32_t want = (t.own_off(cur)[i + 1] - t.own_off(cur)[i]) + (t.inc_off[i + 1] - t.inc_off[i]);
+                    short_ |= t.done[i] != want;
+                }
+                (void)solved;
+                if (__syncthreads_or(short_)) {  // cannot happen with consistent lists
+                    if (tid == 0) atomicExch(&A.status->fail_stall, 1);
+                    return;
+                }
             }
-            __syncthreads();
 
             // ------------------------------ clear policy between passes, L:1905-1912
             if (c + 1 < A.n_collision_steps) {
@@ -693,9 +762,9 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
         }
 
         // ------------------------------------------------ post-solve, L:1690-1693
-        for (int i = lane; i < n; i += EGG_WAVE) {
-            t.vx[i] = (t.x[i] - t.px[i]) / sub_delta;
-            t.vy[i] = (t.y[i] - t.py[i]) / sub_delta;
+        for (int i = tid; i < n; i += nthreads) {
+            double2 ps = t.pos[i], pv = t.prev[i];
+            t.vel[i] = make_double2((ps.x - pv.x) / sub_delta, (ps.y - pv.y) / sub_delta);
         }
         __syncthreads();
     }
@@ -709,16 +778,16 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
         int l0 = t.aoff[k], cnt = t.aoff[k + 1] - l0;
         const int32_t *cl = &t.aclaim[4 * k];
         int lo_x = 0x7FFFFFFF, lo_y = 0x7FFFFFFF, hi_x = -0x7FFFFFFF, hi_y = -0x7FFFFFFF;
-        for (int q = lane; q < cnt; q += EGG_WAVE) {
+        for (int q = tid; q < cnt; q += nthreads) {
             int i = l0 + q;
             if (i >= n) break;
             int g = g0 + q;
-            double x = t.x[i], y = t.y[i];
-            A.x_out[g] = x;
-            A.y_out[g] = y;
-            A.vx_out[g] = t.vx[i];
-            A.vy_out[g] = t.vy[i];
-            double fcx = floor(x / A.cell_size), fcy = floor(y / A.cell_size);
+            double2 ps = t.pos[i], v = t.vel[i];
+            A.x_out[g] = ps.x;
+            A.y_out[g] = ps.y;
+            A.vx_out[g] = v.x;
+            A.vy_out[g] = v.y;
+            double fcx = floor(ps.x / A.cell_size), fcy = floor(ps.y / A.cell_size);
             int cx = (fcx >= -2.0e9 && fcx <= 2.0e9) ? (int)fcx : 0x7FFFFFF0;
             int cy = (fcy >= -2.0e9 && fcy <= 2.0e9) ? (int)fcy : 0x7FFFFFF0;
             lo_x = min(lo_x, cx);
@@ -734,12 +803,22 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
             hi_x = max(hi_x, __shfl_xor(hi_x, d, 64));
             hi_y = max(hi_y, __shfl_xor(hi_y, d, 64));
         }
-        if (lane == 0) {
-            A.atom_aabb_out[4 * atom + 0] = lo_x;
-            A.atom_aabb_out[4 * atom + 1] = lo_y;
-            A.atom_aabb_out[4 * atom + 2] = hi_x;
-            A.atom_aabb_out[4 * atom + 3] = hi_y;
+        // the atom's box over all waves of the workgroup, through LDS
+        if (tid == 0) {
+            t.sc[8] = 0x7FFFFFFF;
+            t.sc[9] = 0x7FFFFFFF;
+            t.sc[10] = -0x7FFFFFFF;
+            t.sc[11] = -0x7FFFFFFF;
         }
+        __syncthreads();
+        if (lane == 0 && lo_x != 0x7FFFFFFF) {
+            atomicMin(&t.sc[8], lo_x);
+            atomicMin(&t.sc[9], lo_y);
+            atomicMax(&t.sc[10], hi_x);
+            atomicMax(&t.sc[11], hi_y);
+        }
+        __syncthreads();
+        if (tid < 4) A.atom_aabb_out[4 * atom + tid] = t.sc[8 + tid];
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) slack = min(slack, __shfl_xor(slack, d, 64));
@@ -748,9 +827,12 @@ extern "C" __global__ void __launch_bounds__(EGG_WAVE) egg_step_kernel(EggStepAr
         atomicMin(&A.status->min_slack, slack);
         if (bad) atomicExch(&A.status->fail_claim, 1);
         atomicMax(&A.status->max_list, (unsigned long long)max_list);
-        atomicAdd(&A.status->rounds, rounds_total);
+        if (tid == 0) atomicAdd(&A.status->rounds, spins_total);
     }
     PROF(9)  // write back
+#ifdef EGG_PROFILE
+    const unsigned long long rounds_total = spins_total;
+#endif
     PROF_FLUSH
 }
 

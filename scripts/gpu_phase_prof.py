@@ -7,8 +7,12 @@ from egg_fluid_simulation_amd import SimulationHandler, _ffi
 import numpy as np
 names = ["load", "pre+follow", "hash", "count", "fill", "budget", "transpose", "dag", "post", "writeback"]
 def run(nb, steps=20):
-    side = int(np.ceil(np.sqrt(nb)))
-    xs = np.array([100 + 160.0 * (k % side) for k in range(nb)]); ys = np.array([100 + 160.0 * (k // side) for k in range(nb)])
+    side = int(np.ceil(np.sqrt(abs(nb))))
+    if nb < 0:  # -k: k batches overlapping in one island
+        nb = -nb
+        xs = np.array([10.0 + 50 * k for k in range(nb)]); ys = np.array([10.0] * nb)
+    else:
+        xs = np.array([100 + 160.0 * (k % side) for k in range(nb)]); ys = np.array([100 + 160.0 * (k // side) for k in range(nb)])
     h = SimulationHandler(); h.set_option(_ffi.OPT_TIMING, 1)
     h.add_many(xs, ys, 50, 15)
     for _ in range(5): h.step()

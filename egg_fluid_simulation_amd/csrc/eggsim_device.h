@@ -51,12 +51,26 @@ struct EggStepArgs {
     int32_t use_grid;  // 1: cells are a dense grid over the tile's claim box, 0: open-addressing hash
     int32_t lcap;      // visit-list entries per pass (capacity)
     EggStatus *status;
+    unsigned char *scratch;  // egg_step_kernel_gl: n_tiles slices of egg_step_scratch_bytes()
 };
 
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
 static inline size_t egg_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// bytes of one tile's slice of EggStepArgs::scratch (visit lists in global memory)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline size_t egg_step_scratch_bytes(int lcap, int single_tile) {
+    size_t l = (size_t)lcap;
+    return 2 * ((l * 4 + 15) & ~(size_t)15) + ((((single_tile ? 2 : 1) * l * 2) + 15) & ~(size_t)15);
+}
+
 // dynamic LDS bytes the step kernel carves for the geometry above (must match eggsim_step.hip)
-static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_grid, int lcap, int single_tile) {
+static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_grid, int lcap, int single_tile,
+                                        int global_lists) {
     size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, l = (size_t)lcap;
     size_t b = 0;
     b += 4 * egg_align16(n * 16);            // pos wr prev vel
@@ -67,14 +81,14 @@ static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_gr
     b += egg_align16(2 * (n + 1) * 4);       // own_off[2]
     b += egg_align16((n + 1) * 4);           // inc_off
     b += 2 * egg_align16(n * 4);             // fill done
-    b += 2 * egg_align16(l * 4);             // own_pack inc_tmp
+    if (!global_lists) b += 2 * egg_align16(l * 4);  // own_pack inc_tmp
     b += egg_align16(a * 4 * 4);             // aclaim
     b += egg_align16((a + 1) * 4);           // aoff
     b += egg_align16(a * 4);                 // abatch
     b += egg_align16(16 * 4);                // scalars
     b += egg_align16(2 * n * 2);             // hitems[2]
     b += 3 * egg_align16(n * 2);             // pslot aslot nlo
-    b += egg_align16((single_tile ? 2 : 1) * l * 2);  // own_ent
+    if (!global_lists) b += egg_align16((single_tile ? 2 : 1) * l * 2);  // own_ent
     return b;
 }
 

@@ -22,6 +22,7 @@
 #include "eggsim_device.h"
 
 extern "C" __global__ void egg_step_kernel(EggStepArgs A);
+extern "C" __global__ void egg_step_kernel_gl(EggStepArgs A);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
                                                    int, double, int32_t *);
 extern "C" __global__ void egg_rederive_kernel(const double *, double *, double *, int, int, double, double, int,
@@ -90,7 +91,8 @@ struct Box {
 struct LaunchClass {  // tiles of similar size share a launch (uniform LDS geometry)
     int first_tile = 0, n_tiles = 0;
     int nmax = 0, amax = 0, ccap = 0, use_grid = 0, lcap = 0;
-    size_t lds = 0;
+    int global_lists = 0;  // visit lists in the scratch buffer instead of LDS
+    size_t lds = 0, scratch_offset = 0;
 };
 
 struct System {  // one particle type
@@ -109,6 +111,7 @@ struct System {  // one particle type
     // tiles
     std::vector<int32_t> tile_atom_begin, tile_atoms;
     DevBuf<int32_t> d_tile_atom_begin, d_tile_atoms;
+    DevBuf<unsigned char> d_scratch;
     std::vector<LaunchClass> classes;
     int margin = 2;
     int single_tile = 0;  // exact-budget mode: everything in one tile
@@ -512,6 +515,7 @@ int retile(egg_handle *h, int which) {
     }
     // launch classes: consecutive tiles whose particle count is within 2x
     size_t t0 = 0;
+    size_t scratch_bytes = 0;
     while (t0 < tiles.size()) {
         size_t t1 = t0;
         int64_t nmax = tiles[t0].particles;
@@ -542,15 +546,26 @@ int retile(egg_handle *h, int which) {
         lcap = std::min<size_t>(lcap, kMaxListEntries);
         lcap = (lcap + 7) & ~(size_t)7;
         lc.lcap = (int)lcap;
-        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0);
+        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0);
+        if (lc.lds > h->lds_limit || lc.lds > 96 * 1024) {
+            // dense or large tiles: particle state stays in LDS, the visit lists go to global memory
+            lc.global_lists = 1;
+            lcap = std::max<size_t>({lcap, (size_t)(32.0 * lc.nmax), s.list_min});
+            lcap = std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxListEntries);
+            lc.lcap = (int)lcap;
+            lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1);
+            lc.scratch_offset = scratch_bytes;
+            scratch_bytes += (size_t)lc.n_tiles * egg_step_scratch_bytes(lc.lcap, single ? 1 : 0);
+        }
         if (lc.lds > h->lds_limit)
             return fail(h, EGG_ERR_UNSUPPORTED,
-                        "a tile of %d particles with %d visit-list entries needs %zu bytes of LDS (limit %zu)",
-                        lc.nmax, lc.lcap, lc.lds, h->lds_limit);
+                        "a tile of %d particles needs %zu bytes of LDS for its particle state (limit %zu)", lc.nmax,
+                        lc.lds, h->lds_limit);
         s.classes.push_back(lc);
         t0 = t1;
     }
 
+    HIP_TRY(h, s.d_scratch.reserve(scratch_bytes + 16, false, s.stream));
     HIP_TRY(h, s.d_tile_atom_begin.reserve(s.tile_atom_begin.size(), false, s.stream));
     HIP_TRY(h, s.d_tile_atoms.reserve(s.tile_atoms.size() + 1, false, s.stream));
     HIP_TRY(h, hipMemcpy(s.d_tile_atom_begin.p, s.tile_atom_begin.data(), s.tile_atom_begin.size() * 4,
@@ -638,8 +653,13 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.use_grid = lc.use_grid;
         A.lcap = lc.lcap;
         A.status = s.d_status;
-        hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax)), lc.lds,
-                           s.stream, A);
+        A.scratch = s.d_scratch.p + lc.scratch_offset;
+        if (lc.global_lists)
+            hipLaunchKernelGGL(egg_step_kernel_gl, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax)),
+                               lc.lds, s.stream, A);
+        else
+            hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax)),
+                               lc.lds, s.stream, A);
         HIP_TRY(h, hipGetLastError());
         h->stats.kernel_launches++;
     }
@@ -850,6 +870,8 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
     // runtime grants for this kernel
     for (size_t want = kLdsMax; want > h->lds_limit; want -= 16 * 1024) {
         e = hipFuncSetAttribute((const void *)egg_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_gl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess) {
             h->lds_limit = want;
             break;

@@ -381,9 +381,13 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
     return solved;
 }
 
-}  // namespace
-
-extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel(EggStepArgs A) {
+// GLOBAL_LISTS = false: everything in LDS.  GLOBAL_LISTS = true: the visit lists (own_pack, inc_tmp,
+// own_ent) live in a per-tile slice of A.scratch; they are written once per pass and read back
+// sequentially, and the pair scheduler prefetches its next entry, so HBM/L2 latency stays off
+// the critical path.  Dense tiles (several coincident batches) need this: their lists alone
+// exceed the LDS a workgroup may have.
+template <bool GLOBAL_LISTS>
+__device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -411,8 +415,10 @@ extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel(EggStepArgs A
         t.inc_off = (uint32_t *)carve(p, (n + 1) * 4);
         t.fill = (uint32_t *)carve(p, n * 4);
         t.done = (uint32_t *)carve(p, n * 4);
-        t.own_pack = (uint32_t *)carve(p, l * 4);
-        t.inc_tmp = (uint32_t *)carve(p, l * 4);
+        if (!GLOBAL_LISTS) {
+            t.own_pack = (uint32_t *)carve(p, l * 4);
+            t.inc_tmp = (uint32_t *)carve(p, l * 4);
+        }
         t.aclaim = (int32_t *)carve(p, a * 4 * 4);
         t.aoff = (int32_t *)carve(p, (a + 1) * 4);
         t.abatch = (int32_t *)carve(p, a * 4);
@@ -421,7 +427,14 @@ extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel(EggStepArgs A
         t.pslot = (uint16_t *)carve(p, n * 2);
         t.aslot = (uint16_t *)carve(p, n * 2);
         t.nlo = (uint16_t *)carve(p, n * 2);
-        t.own_ent_b = (uint16_t *)carve(p, (A.single_tile ? 2 : 1) * l * 2);
+        if (!GLOBAL_LISTS) {
+            t.own_ent_b = (uint16_t *)carve(p, (A.single_tile ? 2 : 1) * l * 2);
+        } else {
+            unsigned char *g = A.scratch + (size_t)tile * egg_step_scratch_bytes(A.lcap, A.single_tile);
+            t.own_pack = (uint32_t *)g;
+            t.inc_tmp = (uint32_t *)(g + egg_align16(l * 4));
+            t.own_ent_b = (uint16_t *)(g + 2 * egg_align16(l * 4));
+        }
         t.s_n = (int)n;
         t.s_c = (int)cc;
         t.s_o = (int)n + 1;
@@ -835,6 +848,11 @@ extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel(EggStepArgs A
 #endif
     PROF_FLUSH
 }
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel(EggStepArgs A) { egg_step_body<false>(A); }
+extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true>(A); }
 
 #ifdef EGG_PROFILE
 extern "C" void egg_prof_read(unsigned long long *out) {

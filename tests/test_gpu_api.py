@@ -1,0 +1,127 @@
+"""Behaviour of the SimulationHandler surface on the device path: the reference's defaults,
+warnings, errors, accumulator, add/remove and live config changes (simulation_handler.lua:27-419)."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WHITE, YOLK = 0, 1
+
+
+@pytest.fixture(scope="module")
+def egg():
+    import egg_fluid_simulation_amd as e
+    return e
+
+
+def test_add_defaults_counts_and_ids(egg):
+    h = egg.SimulationHandler()
+    a = h.add(10, 20)  # white radius 15 * 4 = 60, yolk 60 / 5 = 12 (L:41-47)
+    b = h.add(500, 20, 50, 15)
+    assert (a, b) == (1, 2) and h.list_ids() == [1, 2]
+    assert h.get_n_particles(a) == (225, 9) and h.get_n_particles(b) == (157, 15)
+    assert h.get_n_particles() == (382, 24)
+    assert h.get_target_position(a) == (10.0, 20.0)
+    x, y = h.get_position(a)
+    assert abs(x - 10) < 1 and abs(y - 20) < 1
+
+
+def test_error_and_warning_conventions(egg):
+    h = egg.SimulationHandler()
+    a = h.add(0, 0, 50, 15)
+    with pytest.raises(egg.EggError, match="white radius cannot be 0 or negative"):
+        h.add(0, 0, -1, 5)
+    with pytest.raises(egg.EggError, match="yolk particle count cannot be 1 or negative"):
+        h.add(0, 0, 50, 15, None, None, 20, 1)
+    with pytest.warns(egg.EggWarning, match="only 7 white / 3 yolk"):
+        c = h.add(300, 0, 10, 6)  # ceil(100/16) = 7 < 10, ceil(36/16) = 3 < 5: warning, batch still created
+    assert h.get_n_particles(c) == (7, 3)
+    with pytest.warns(egg.EggWarning, match="set_target_position: no batch with id"):
+        h.set_target_position(99, 1, 2)  # warning, no throw (L:259)
+    with pytest.warns(egg.EggWarning, match="remove: no batch with id"):
+        h.remove(99)
+    for fn in (h.get_position, h.get_target_position, h.get_n_particles):
+        with pytest.raises(egg.EggError, match="no batch with id"):
+            fn(99)
+    with pytest.raises(egg.EggError, match="`step_delta` is not a number > 0"):
+        h.update(0.1, -1)
+    with pytest.raises(egg.EggError, match="`n_substeps` is not a number > 0"):
+        h.update(0.1, 1 / 60, 0)
+    with pytest.raises(egg.EggError, match="`n_collision_steps` is not a number > 0"):
+        h.update(0.1, 1 / 60, 2, 0)
+    assert h.get_position(a)[0] == pytest.approx(0, abs=1)
+
+
+def test_update_accumulator(egg):
+    h = egg.SimulationHandler()
+    h.add(0, 0, 50, 15)
+    assert sum(h.update(1 / 60) for _ in range(100)) == 100 and h.elapsed == 0.0
+    assert h.update(1.0) == 5 and h.elapsed == 0.0  # death-spiral guard (L:203-213)
+    assert h.update(0.01) == 0 and h.interpolation_alpha == pytest.approx(0.6)
+    assert h.update(0.01, 1 / 60, 1.2, 2.5) == 1  # counts are ceil'ed (L:181-182)
+
+
+def test_remove_and_add_between_steps_match_oracle(egg, oracle_mod):
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    ids = [h.add(120.0 * k, 0, 50, 15) for k in range(4)]
+    for k in range(4):
+        o.add(120.0 * k, 0, 50, 15)
+    for _ in range(5):
+        h.update(1 / 60)
+        o.update(1 / 60)
+    h.remove(ids[1])
+    o.remove(ids[1])
+    n = h.add(1000, 50, 50, 15)
+    assert n == o.add(1000, 50, 50, 15) == 5
+    assert h.list_ids() == [1, 3, 4, 5]
+    for _ in range(5):
+        h.update(1 / 60)
+        o.update(1 / 60)
+    for w in (WHITE, YOLK):
+        assert np.array_equal(h.download(w, "x"), o.positions(w)[0])
+        assert np.array_equal(h.download(w, "batch_id"), o.field(w, "batch_id"))
+    for i in h.list_ids():
+        assert h.get_position(i) == o.get_position(i)
+
+
+def test_live_config_change_rederives_mass_and_radius(egg, oracle_mod):
+    from egg_fluid_simulation_amd.default_config import default_configs
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    h.add(0, 0, 50, 15)
+    o.add(0, 0, 50, 15)
+    for _ in range(3):
+        h.update(1 / 60)
+        o.update(1 / 60)
+    w, _ = default_configs()
+    w.update(max_mass=3.0, min_radius=3.0, max_radius=5.0, damping=0.3, collision_strength=0.9)
+    h.set_white_config(w)
+    o.set_config(WHITE, dict(oracle_mod.DEFAULT_WHITE, max_mass=3.0, min_radius=3.0, max_radius=5.0, damping=0.3,
+                             collision_strength=0.9))
+    assert h.get_white_config()["max_mass"] == 3.0
+    for _ in range(4):
+        h.update(1 / 60)
+        o.update(1 / 60)
+    for f in ("x", "y", "radius", "inv_mass"):
+        assert np.array_equal(h.download(WHITE, f), o.field(WHITE, f)), f
+
+
+def test_instance_record_and_last_positions(egg, oracle_mod):
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    h.add(50, 60, 50, 15)
+    o.add(50, 60, 50, 15)
+    for _ in range(3):
+        h.update(1 / 60)
+        o.update(1 / 60)
+    rec = h.download_instance_data(WHITE)
+    assert rec.shape == (157, 7)
+    for col, f in enumerate(("x", "y", "last_x", "last_y", "vx", "vy", "radius")):
+        assert np.array_equal(rec[:, col], o.field(WHITE, f)), f
+
+
+def test_unsupported_configuration_fails_loudly(egg):
+    h = egg.SimulationHandler()
+    h.add(0, 0, 50, 15)
+    with pytest.raises(egg.EggError, match="not implemented on the device path"):
+        h.update(1 / 60, 1 / 60, 3, 1)

@@ -1,0 +1,218 @@
+"""CPU oracle (oracle/eggsim_oracle.c) against the golden vectors of the independent Python
+transliteration, plus the known-answer tests of SURVEY.md 8c.  No GPU needed.
+
+"Parity unpinned": the reference has no tests or fixtures and cannot be run here (no Lua), so
+these pin the oracle to (a) a second, independently written restatement and (b) closed forms
+derived from the reference's source text."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden, replay_golden
+
+WHITE, YOLK = 0, 1
+
+
+def _positions(o, w):
+    return np.array([o.field(w, "x"), o.field(w, "y"), o.field(w, "vx"), o.field(w, "vy")])
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_matches_golden_bit_for_bit(oracle_mod, name):
+    g = load_golden(name)
+    o = oracle_mod.Oracle()
+    visits = []
+
+    def check(step, tag, arr):
+        assert np.array_equal(arr, g["%s_step%d" % (tag, step)]), (name, step, tag)
+
+    centers = [tuple(c) for c in g["centers"]]
+    # replay by hand to also compare per-pass visit counts
+    ids = [o.add(cx, cy, 50, 15) for cx, cy in centers]
+    from conftest import circle_target
+    for k in range(int(g["n_steps"])):
+        if bool(g["moving"]):
+            for i, c in zip(ids, centers):
+                o.set_target_position(i, *circle_target(c, k))
+        o.update(1 / 60, 1 / 60, int(g["substeps"]), int(g["collision_steps"]))
+        visits.append([s["n_visited"] for s in o.pass_stats()])
+        if k + 1 in set(int(s) for s in g["snap_steps"]):
+            for w, tag in ((0, "white"), (1, "yolk")):
+                check(k + 1, tag, _positions(o, w))
+            cen = np.array([o.get_position(i) for i in ids])
+            assert np.array_equal(cen, g["centroid_step%d" % (k + 1)])
+    assert np.array_equal(np.array(visits), g["visits"])
+
+
+def test_initial_state_matches_golden(oracle_mod):
+    g = load_golden("cfg1_static")
+    o = oracle_mod.Oracle()
+    o.add(400, 300, 50, 15)
+    for w, key in ((WHITE, "init_white"), (YOLK, "init_yolk")):
+        got = np.array([o.field(w, f) for f in ("x", "y", "mass_t", "inv_mass", "radius")])
+        assert np.array_equal(got, g[key])
+
+
+# ---- SURVEY 8c known-answer tests -------------------------------------------------------
+
+def test_ka1_particle_counts(oracle_mod):
+    o = oracle_mod.Oracle()
+    o.add(0, 0, 50, 15)
+    assert (o.n_particles(WHITE), o.n_particles(YOLK)) == (157, 15)
+    o2 = oracle_mod.Oracle()
+    o2.add(0, 0, 60, 12)  # the reference's defaults: 15 * r and white / 5
+    assert (o2.n_particles(WHITE), o2.n_particles(YOLK)) == (225, 9)
+
+
+def test_ka2_compliances(oracle_mod):
+    o = oracle_mod.Oracle()
+    o.add(0, 0, 50, 15)
+    o.update(1 / 60)
+    w, y = o.env(WHITE), o.env(YOLK)
+    for got, want in ((w["follow_compliance"], 57.6), (w["collision_compliance"], 36.0),
+                      (w["cohesion_compliance"], 2880.0), (y["collision_compliance"], 14.4),
+                      (y["cohesion_compliance"], 28.8)):
+        assert got == pytest.approx(want, rel=1e-12)
+    assert w["damping"] == 0.9 and w["cell_radius"] == 8.0 and y["cell_radius"] == 12.0
+    assert w["max_n_collisions"] == pytest.approx(0.05 * 157 ** 2) and y["max_n_collisions"] == 11.25
+
+
+def test_ka3_first_particle_at_centre(oracle_mod):
+    o = oracle_mod.Oracle()
+    o.add(123.5, -77.25, 50, 15)
+    assert (o.field(WHITE, "x")[0], o.field(WHITE, "y")[0]) == (123.5, -77.25)
+    assert (o.field(YOLK, "x")[0], o.field(YOLK, "y")[0]) == (123.5, -77.25)
+
+
+def test_ka4_mass_distribution(oracle_mod):
+    o = oracle_mod.Oracle()
+    o.add(0, 0, 50, 15)
+    t = o.field(WHITE, "mass_t")
+    assert 0.058 < t[0] < 0.065 and 0.058 < t[-1] < 0.062
+    assert t.max() > 0.999 and int(np.argmax(t)) + 1 in (78, 79)
+    assert np.allclose(1 / o.field(WHITE, "inv_mass"), 1 + 0.8 * t, rtol=1e-15)
+    assert np.allclose(1 / o.field(YOLK, "inv_mass"), 1 + 0.35 * o.field(YOLK, "mass_t"), rtol=1e-15)
+
+
+def test_ka5_two_particle_closed_form(oracle_mod):
+    # One batch of n=2 white particles: particle 1 at the centre, particle 2 at r = sqrt(1/2) * R.
+    # R = 4 keeps the follow constraint inactive (distance 2.83 <= slack 2 * sqrt(4) = 4).
+    R = 4.0
+    cfg = dict(oracle_mod.DEFAULT_WHITE, min_mass=1, max_mass=1)
+    o = oracle_mod.Oracle(cfg, cfg)
+    o.add(0, 0, R, R, 2, 2)
+    x0, y0 = o.positions(WHITE)
+    d = math.hypot(x0[1] - x0[0], y0[1] - y0[0])
+    assert d == pytest.approx(R * math.sqrt(0.5)) and d < 16
+    o.step(1 / 60, 1, 1)  # one sub-step, one pass: v = 0, follow inactive, exactly one projection
+    x1, y1 = o.positions(WHITE)
+    w = 1.0
+    move = w * (16 - d) / (2 * w + 3600 * (1 - (1 - 0.0025)))  # compliance = 0.0025 / (1/60)^2 = 9
+    assert 3600 * 0.0025 == pytest.approx(9.0)
+    assert math.hypot(x1[0] - x0[0], y1[0] - y0[0]) == pytest.approx(move, rel=1e-12)
+    assert math.hypot(x1[1] - x0[1], y1[1] - y0[1]) == pytest.approx(move, rel=1e-12)
+    d1 = math.hypot(x1[1] - x1[0], y1[1] - y1[0])
+    assert d1 == pytest.approx(d + 2 * move, rel=1e-12)
+
+
+def test_ka6_follow_closed_form(oracle_mod):
+    # two particles 21.2 px apart (> the 16 px collision range), so only the follow constraint acts
+    cfg = dict(oracle_mod.DEFAULT_WHITE, min_mass=1, max_mass=1)
+    R = 30.0
+    o = oracle_mod.Oracle(cfg, cfg)
+    b = o.add(0, 0, R, R, 2, 2)
+    o.set_target_position(b, 100.0, 0.0)
+    o.step(1 / 60, 1, 1)
+    x, y = o.positions(WHITE)
+    # particle 1 started at the centre: d = 100, slack 2 * sqrt(R), compliance 0.004 * 3600 = 14.4
+    assert x[0] == pytest.approx((100 - 2 * math.sqrt(R)) * 1.0 / (1.0 + 14.4), rel=1e-12) and y[0] == 0.0
+    # no move when d <= 2 sqrt(R)
+    o2 = oracle_mod.Oracle(cfg, cfg)
+    b2 = o2.add(0, 0, R, R, 2, 2)
+    o2.set_target_position(b2, 10.9, 0.0)
+    before = o2.positions(WHITE)[0][0]
+    o2.step(1 / 60, 1, 1)
+    assert o2.positions(WHITE)[0][0] == before
+
+
+def test_ka7_ka8_budget_and_stale_pass(oracle_mod):
+    o = oracle_mod.Oracle()
+    o.add(400, 300, 50, 15)
+    o.update(1 / 60)
+    st = o.pass_stats()
+    yolk = [s for s in st if s["which"] == YOLK]
+    white = [s for s in st if s["which"] == WHITE]
+    assert [s["n_visited"] for s in yolk] == [12] * 6 and all(s["cut"] for s in yolk)  # Q2: 11.25 -> 12
+    v = [s["n_visited"] for s in white]
+    # Q3: the first pass of sub-step 2 only visits what the previous pass did not
+    assert v[3] < 0.5 * min(v[0], v[1], v[2], v[4], v[5]) and not any(s["cut"] for s in white)
+    # the stale yolk pass visits the NEXT 12 pairs
+    o.set_trace(True)
+    o.update(1 / 60)
+    tr = o.trace()
+    ps = o.pass_stats()
+    y_idx = [k for k, s in enumerate(ps) if s["which"] == YOLK]
+    third = {(int(a), int(b)) for a, b in tr[tr["pass_seq"] == y_idx[2]][["self_i", "other_i"]].tolist()}
+    fourth = {(int(a), int(b)) for a, b in tr[tr["pass_seq"] == y_idx[3]][["self_i", "other_i"]].tolist()}
+    assert len(third) == 12 and len(fourth) == 12 and not (third & fourth)
+
+
+def test_ka9_cohesion_is_dead(oracle_mod):
+    def run(**over):
+        w = dict(oracle_mod.DEFAULT_WHITE, **over)
+        o = oracle_mod.Oracle(w, oracle_mod.DEFAULT_YOLK)
+        o.add(400, 300, 50, 15)
+        for _ in range(10):
+            o.update(1 / 60)
+        return o.positions(WHITE)
+    base = run()
+    other = run(cohesion_strength=0.1)
+    assert np.array_equal(base[0], other[0]) and np.array_equal(base[1], other[1])
+    cells = run(cohesion_interaction_distance_factor=3)  # only changes the cell size
+    assert not np.array_equal(base[0], cells[0])
+
+
+def test_ka10_coincident_particles_never_separate(oracle_mod):
+    # two 2-particle batches on the same centre: each particle coincides with its twin and is more
+    # than the 16 px collision range away from everything else, so the only projections are between
+    # coincident particles, where normalize() returns (0, 0) (math.lua:53-56): no correction, ever
+    o = oracle_mod.Oracle()
+    o.add(0, 0, 40.0, 40.0, 2, 2)
+    o.add(0, 0, 40.0, 40.0, 2, 2)
+    for _ in range(5):
+        o.update(1 / 60)
+        x, y = o.positions(WHITE)
+        assert x[0] == x[2] and y[0] == y[2] and x[1] == x[3] and y[1] == y[3]
+    st = [s for s in o.pass_stats() if s["which"] == WHITE]
+    assert all(s["n_visited"] >= 1 for s in st[:3])  # the coincident pairs ARE visited
+
+
+def test_ka11_negative_coordinates(oracle_mod):
+    g = load_golden("cfg1_origin")
+    assert (g["white_step1"][0] < 0).any() and (g["white_step1"][1] < 0).any()
+
+
+def test_ka12_update_accumulator(oracle_mod):
+    o = oracle_mod.Oracle()
+    o.add(0, 0, 50, 15)
+    assert sum(o.update(1 / 60) for _ in range(100)) == 100
+    assert o.elapsed == 0.0
+    o2 = oracle_mod.Oracle()
+    o2.add(0, 0, 50, 15)
+    assert o2.update(1.0) == 5 and o2.elapsed == 0.0  # death-spiral guard (L:203-213)
+    o3 = oracle_mod.Oracle()
+    assert o3.update(0.01) == 0 and o3.interpolation_alpha == pytest.approx(0.6)
+
+
+def test_remove_preserves_order(oracle_mod):
+    o = oracle_mod.Oracle()
+    ids = [o.add(100.0 * k, 0, 50, 15) for k in range(3)]
+    x_before = o.field(WHITE, "x")
+    assert o.remove(ids[1]) == 0 and o.remove(ids[1]) == 1
+    x_after = o.field(WHITE, "x")
+    assert np.array_equal(x_after, np.concatenate([x_before[:157], x_before[314:]]))
+    assert o.n_batches() == 2 and np.array_equal(np.unique(o.field(WHITE, "batch_id")), [1.0, 3.0])
+    for _ in range(3):
+        o.update(1 / 60)
+    assert o.get_position(ids[2])[0] == pytest.approx(200, abs=5)

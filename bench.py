@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the XPBD particle step on MI355X (driver contract: one JSON line on rank 0).
+
+    python bench.py                       # 1 GPU, BASELINE config 2 (256 non-overlapping batches)
+    python bench.py --batches 4096        # other batch counts (not the headline config)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one SimulationHandler:_step (dt = 1/60, 2 sub-steps x 3 collision passes,
+simulation_handler.lua:1722) over every particle of the workload.  Inputs are resident in HBM
+before the timed region (the handler owns the particle arrays on the device).
+
+Multi-GPU: the plane is cut into N x-slabs of `--batches` batches each (weak scaling); every
+rank steps its slab with its own handler and the ranks exchange the cell boxes of their
+slab-boundary batches once per step (egg_fluid_simulation_amd/sharding.py) -- the only
+cross-rank data the path needs while no batch crosses a cut.
+
+value = pair solves (visited pairs, simulation_handler.lua:1657) per second over ALL ranks;
+steps_per_sec is the lock-step rate of the whole job.  The reference Lua path cannot be timed
+(no Lua interpreter in this pipeline); cpu_baseline times the sequential C restatement
+(oracle/, single thread because the reference is single-threaded) on the same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_PARTICLE_STEP = 592.0  # SURVEY.md 8d / BASELINE.md: FP64 SoA, state round-trips HBM once per phase
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
+PITCH = 160.0                         # px between batch centres (BASELINE config 2: islands never touch)
+
+
+def grid_positions(n_batches, column_offset=0):
+    side = int(math.ceil(math.sqrt(n_batches)))
+    k = np.arange(n_batches)
+    xs = 100.0 + PITCH * (k % side + column_offset * side)
+    ys = 100.0 + PITCH * (k // side)
+    return xs.astype(np.float64), ys.astype(np.float64), side
+
+
+def cpu_baseline(n_batches, budget_s=12.0):
+    """The CPU oracle on the same workload, single thread, bounded to ~budget_s seconds."""
+    from oracle.oracle import Oracle
+    xs, ys, _ = grid_positions(n_batches)
+    o = Oracle()
+    for x, y in zip(xs, ys):
+        o.add(float(x), float(y), 50, 15)
+    warm = 2
+    for _ in range(warm):
+        o.update(1 / 60)
+    v0 = o.total_visited
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        o.update(1 / 60)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or steps >= 400:
+            break
+    pairs = o.total_visited - v0
+    return {"value": pairs / dt, "unit": "pair-solves/s", "cores": 1, "kind": "port",
+            "steps_per_sec": steps / dt,
+            "sample": "oracle/eggsim_oracle.c (sequential C restatement of the Lua step; the Lua reference itself "
+                      "cannot run here), same %d-batch workload, %d timed steps after %d warm-up, 1 thread of %d host "
+                      "cores" % (n_batches, steps, warm, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batches", type=int, default=256, help="batches per GPU (256 = BASELINE config 2)")
+    ap.add_argument("--tile-target", type=int, default=0, help="pack independent islands into tiles of this size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" %
+                         (args.gpus, args.gpus, world))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")  # RCCL on ROCm
+
+    from egg_fluid_simulation_amd import WHITE, YOLK, SimulationHandler, _ffi
+    from egg_fluid_simulation_amd.sharding import BoundaryExchange
+
+    h = SimulationHandler(device=local_rank)  # raises without a GPU: no CPU path
+    if args.tile_target:
+        h.set_option(_ffi.OPT_TILE_TARGET_PARTICLES, args.tile_target)
+    xs, ys, side = grid_positions(args.batches, column_offset=rank)
+    ids = h.add_many(xs, ys, 50, 15)
+    n_white, n_yolk = h.get_n_particles()
+    halo = BoundaryExchange(h, rank, world, slab_lo=100.0 + PITCH * rank * side - PITCH / 2,
+                            slab_hi=100.0 + PITCH * (rank + 1) * side - PITCH / 2, group=dist) if world > 1 else None
+
+    def one_step():
+        if halo is not None:
+            halo.exchange()  # neighbours' boundary batch boxes; asserts that no batch straddles a cut
+        h.step(1 / 60, 2, 3)
+
+    for _ in range(args.warmup):
+        one_step()
+    h.set_option(_ffi.OPT_TIMING, 1)  # HIP events around the step launches, on the streams they run on
+    h.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    s0 = h.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    h.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    s1 = h.stats()
+
+    pairs = float(s1["pair_solves"] - s0["pair_solves"])
+    follows = float(s1["follow_solves"] - s0["follow_solves"])
+    kernel_ms_white = s1["kernel_ms_sum"][WHITE] / max(1, s1["timed_steps"])
+    kernel_ms_yolk = s1["kernel_ms_sum"][YOLK] / max(1, s1["timed_steps"])
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        agg = torch.tensor([pairs, follows, float(n_white + n_yolk)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        pairs, follows, total_particles = (float(v) for v in agg.tolist())
+    else:
+        total_particles = float(n_white + n_yolk)
+
+    if rank == 0:
+        steps_per_sec = args.steps / elapsed
+        # roofline of the dominant kernel (the white-particle launch of egg_step_kernel on this rank):
+        # algorithmic bytes of one launch / its average HIP-event duration
+        algo_bytes = ALGO_BYTES_PER_PARTICLE_STEP * n_white
+        achieved = algo_bytes / (kernel_ms_white * 1e-3) / 1e9 if kernel_ms_white > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and args.batches == 256 and world == 1:
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "pair_solves_per_sec", "value": pairs / elapsed, "unit": "pair-solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "steps_per_sec": steps_per_sec,
+            "constraint_solves_per_sec": (pairs + follows) / elapsed,
+            "particles": int(total_particles),
+            "config": {"workload": "BASELINE config 2: %d non-overlapping batches per GPU (white r=50, yolk r=15) on a "
+                                   "%.0f px grid, default config, dt=1/60, 2 sub-steps x 3 collision passes"
+                                   % (args.batches, PITCH),
+                       "batches_per_gpu": args.batches, "particles_per_gpu": int(n_white + n_yolk),
+                       "parallelism": "slab%d" % world, "tiles": s1["n_tiles"], "retiles": s1["retiles"] - s0["retiles"],
+                       "redo_steps": s1["redo_steps"] - s0["redo_steps"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "egg_step_kernel (white launch)", "kernel_ms": kernel_ms_white,
+                         "kernel_ms_yolk_launch": kernel_ms_yolk, "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "592 B/particle/step byte model of SURVEY.md 8d; the fused kernel moves far fewer "
+                                 "HBM bytes and is bound by the serial pair-dependency chain in FP64, see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.batches)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

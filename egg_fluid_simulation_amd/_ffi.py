@@ -46,7 +46,8 @@ class EggStats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("pair_solves", C.c_int64), ("follow_solves", C.c_int64),
                 ("kernel_launches", C.c_int64), ("retiles", C.c_int64), ("redo_steps", C.c_int64),
                 ("n_tiles", C.c_int64 * 2), ("max_tile_particles", C.c_int64 * 2),
-                ("last_step_kernel_ms", C.c_double), ("single_tile", C.c_int64 * 2)]
+                ("last_step_kernel_ms", C.c_double), ("single_tile", C.c_int64 * 2),
+                ("kernel_ms", C.c_double * 2), ("kernel_ms_sum", C.c_double * 2), ("timed_steps", C.c_int64)]
 
 
 # every symbol include/eggsim.h declares, with its signature
@@ -70,6 +71,7 @@ _SIGNATURES = {
     "egg_synchronize": (C.c_int, [C.c_void_p]),
     "egg_get_position": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egg_get_positions_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egg_get_bounds_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egg_get_n_particles": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "egg_list_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "egg_get_elapsed": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

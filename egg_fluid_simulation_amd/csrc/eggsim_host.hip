@@ -725,6 +725,7 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
                 float t = 0;
                 HIP_TRY(h, hipEventElapsedTime(&t, s.ev0, s.ev1));
                 ms = std::max(ms, (double)t);
+                h->stats.kernel_ms[w] = (double)t;
             }
             const EggStatus &st = *s.h_status;
             if (st.fail_overflow) {
@@ -798,6 +799,10 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
             h->stats.single_tile[w] = s.single_tile;
         }
         h->stats.last_step_kernel_ms = ms;
+        if (h->opt_timing) {
+            for (int w = 0; w < 2; ++w) h->stats.kernel_ms_sum[w] += h->stats.kernel_ms[w];
+            h->stats.timed_steps++;
+        }
         h->stats.steps++;
         return EGG_OK;
     }
@@ -1162,6 +1167,51 @@ int egg_get_position(egg_handle *h, int64_t id, double *x, double *y) {
     return egg_get_positions_many(h, 1, &id, x, y);
 }
 
+int egg_get_bounds_many(egg_handle *h, int64_t n, const int64_t *ids, double *lo_x, double *lo_y, double *hi_x,
+                        double *hi_y) {
+    if (!h || n < 0 || (n > 0 && (!ids || !lo_x || !lo_y || !hi_x || !hi_y))) return EGG_ERR_INVALID_ARGUMENT;
+    if (n == 0) return EGG_OK;
+    (void)hipSetDevice(h->device);
+    double cell[2];
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        int rc = upload_atoms(h, w);
+        if (rc != EGG_OK) return rc;
+        cell[w] = cell_size_of(s.cfg);
+        const size_t na = s.atoms.size();
+        if (!s.aabb_valid && s.aabb_on_device && s.tiled_cell_size == cell[w]) {
+            rc = fetch_end_aabb(h, s);
+            if (rc != EGG_OK) return rc;
+        }
+        if (!s.aabb_valid && na) {
+            hipLaunchKernelGGL(egg_atom_bounds_kernel, dim3((unsigned)na), dim3(EGG_WAVE), 0, s.stream, s.x[s.cur].p,
+                               s.y[s.cur].p, s.d_atom_offset.p, s.d_atom_count.p, (int)na, cell[w], s.d_atom_aabb.p);
+            HIP_TRY(h, hipGetLastError());
+            h->stats.kernel_launches++;
+            s.aabb.resize(na);
+            HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), s.d_atom_aabb.p, na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(h, hipStreamSynchronize(s.stream));
+            // these are the cells of the CURRENT positions at the CURRENT cell size
+            s.aabb_valid = true;
+            if (s.tiled_cell_size != cell[w]) s.tiling_dirty = true;
+            s.tiled_cell_size = cell[w];
+        }
+    }
+    std::vector<int32_t> atom_of_batch(h->batches.size(), -1);
+    for (size_t k = 0; k < h->sys[0].atoms.size(); ++k) atom_of_batch[(size_t)h->sys[0].atoms[k].batch] = (int32_t)k;
+    for (int64_t k = 0; k < n; ++k) {
+        if (!find_batch(h, ids[k]))
+            return fail(h, EGG_ERR_UNKNOWN_ID, "egg_get_bounds_many: no batch with id `%lld`", (long long)ids[k]);
+        const int32_t a = atom_of_batch[(size_t)ids[k] - 1];
+        const Box &bw = h->sys[0].aabb[(size_t)a], &by = h->sys[1].aabb[(size_t)a];
+        lo_x[k] = std::min(bw.lo_x * cell[0], by.lo_x * cell[1]);
+        lo_y[k] = std::min(bw.lo_y * cell[0], by.lo_y * cell[1]);
+        hi_x[k] = std::max((bw.hi_x + 1.0) * cell[0], (by.hi_x + 1.0) * cell[1]);
+        hi_y[k] = std::max((bw.hi_y + 1.0) * cell[0], (by.hi_y + 1.0) * cell[1]);
+    }
+    return EGG_OK;
+}
+
 int egg_get_n_particles(const egg_handle *h, int64_t id, int64_t *n_white, int64_t *n_yolk) {  // L:409-419
     if (!h || !n_white || !n_yolk) return EGG_ERR_INVALID_ARGUMENT;
     if (id < 0) {
@@ -1254,6 +1304,8 @@ int egg_set_option(egg_handle *h, int option, double value) {
             return EGG_OK;
         case EGG_OPT_TIMING:
             h->opt_timing = value != 0;
+            h->stats.kernel_ms_sum[0] = h->stats.kernel_ms_sum[1] = 0;
+            h->stats.timed_steps = 0;
             return EGG_OK;
         case EGG_OPT_FORCE_SINGLE_TILE:
             h->opt_force_single = value != 0;

@@ -306,6 +306,14 @@ class SimulationHandler:
                                                      ys.ctypes.data))
         return xs, ys
 
+    def get_bounds(self, ids):
+        """[n, 4] array (lo_x, lo_y, hi_x, hi_y) in px: the cells each batch's particles occupy."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty((4, ids.shape[0]), dtype=np.float64)
+        self._check(self._lib.egg_get_bounds_many(self._h, ids.shape[0], ids.ctypes.data, out[0].ctypes.data,
+                                                  out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data))
+        return out.T.copy()
+
     # ----------------------------------------------------------------- colors
     # render attributes: kept on the host, never read by the solver (L:297-395)
     def _set_color(self, scope, which, batch_id, r, g, b, a):
@@ -379,7 +387,8 @@ class SimulationHandler:
         return dict(steps=s.steps, pair_solves=s.pair_solves, follow_solves=s.follow_solves,
                     kernel_launches=s.kernel_launches, retiles=s.retiles, redo_steps=s.redo_steps,
                     n_tiles=list(s.n_tiles), max_tile_particles=list(s.max_tile_particles),
-                    last_step_kernel_ms=s.last_step_kernel_ms, single_tile=list(s.single_tile))
+                    last_step_kernel_ms=s.last_step_kernel_ms, single_tile=list(s.single_tile),
+                    kernel_ms=list(s.kernel_ms), kernel_ms_sum=list(s.kernel_ms_sum), timed_steps=s.timed_steps)
 
     def set_option(self, option, value):
         self._check(self._lib.egg_set_option(self._h, int(option), float(value)))

@@ -109,6 +109,12 @@ int egg_synchronize(egg_handle *h);
 int egg_get_position(egg_handle *h, int64_t id, double *x, double *y);
 int egg_get_positions_many(egg_handle *h, int64_t n, const int64_t *ids, double *xs, double *ys);
 
+/* axis-aligned bounds (px) of each batch's particles, white and yolk together, rounded outwards to
+ * the spatial-hash cells they occupy (L:1494-1495).  Used by the multi-GPU slab exchange; the
+ * reference computes the same per-environment AABB in _post_solve (L:1703-1709). */
+int egg_get_bounds_many(egg_handle *h, int64_t n, const int64_t *ids, double *lo_x, double *lo_y,
+                        double *hi_x, double *hi_y);
+
 /* get_n_particles(id) / get_n_particles() with id < 0 (L:409-419) */
 int egg_get_n_particles(const egg_handle *h, int64_t id, int64_t *n_white, int64_t *n_yolk);
 /* list_ids (L:399-405): ids in creation order; returns the count in *n, copies min(*n, cap) ids */
@@ -137,6 +143,9 @@ typedef struct {
     int64_t max_tile_particles[2];
     double last_step_kernel_ms; /* device time of the step kernels of the most recent _step (HIP events) */
     int64_t single_tile[2];  /* 1 if that type currently runs in exact-budget single-tile mode */
+    double kernel_ms[2];     /* device time of that type's step launches in the most recent _step (EGG_OPT_TIMING) */
+    double kernel_ms_sum[2]; /* the same, summed over all committed steps since EGG_OPT_TIMING was switched on */
+    int64_t timed_steps;
 } egg_stats;
 int egg_get_stats(egg_handle *h, egg_stats *out);
 

@@ -329,7 +329,7 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint16_
 
 __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, int nthreads, double overlap,
                                        double compliance, double eps, int total, unsigned int &spins_out) {
-    volatile uint32_t *done = t.done;
+    uint32_t *done = t.done;
     int solved = 0;
     unsigned int spins = 0;
     // A thread walks its particles in ascending order (one particle when n <= nthreads).  That
@@ -353,13 +353,18 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
             const bool live = k < no;
             const int b = live ? (int)(ent & 0xFFFFu) : 0;
             const uint32_t rb = ent >> 16;
-            const uint32_t da = done[as];
-            const uint32_t db = done[b];
+            // relaxed workgroup-scope atomics keep these plain ds_read_b32 / ds_write_b32 (a volatile
+            // access would go through the flat path); ordering is by issue order, see above
+            const uint32_t da = __hip_atomic_load(&done[as], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t db = __hip_atomic_load(&done[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             EGG_COMPILER_BARRIER();  // counters first, then the data they guard
             double2 pa = t.pos[as];
             double2 pb = t.pos[b];
             const double2 wrb = t.wr[b];
             const uint32_t ent_next = t.own_pack[min(o0 + k + 1, t.lcap - 1)];
+            // consume the speculative loads here so that they are issued back to back with the
+            // counters instead of being sunk behind the readiness branch (one LDS latency, not four)
+            __asm__ volatile("" ::"v"(pa.x), "v"(pa.y), "v"(pb.x), "v"(pb.y), "v"(wrb.x), "v"(wrb.y), "v"(ent_next));
             const bool ready = live && da == nl + (uint32_t)k && db == rb;
             if (ready) {
                 if (project_pair(t, a, b, pa, pb, wra, wrb, overlap, compliance, eps)) {
@@ -367,8 +372,8 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
                     t.pos[b] = pb;
                 }
                 EGG_COMPILER_BARRIER();  // data first, then the counters that publish it
-                done[a] = da + 1;
-                done[b] = db + 1;
+                __hip_atomic_store(&done[a], da + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&done[b], db + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ++k;
                 ent = ent_next;
                 ++solved;

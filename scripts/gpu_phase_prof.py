@@ -15,14 +15,15 @@ def run(nb, steps=20):
         xs = np.array([100 + 160.0 * (k % side) for k in range(nb)]); ys = np.array([100 + 160.0 * (k // side) for k in range(nb)])
     h = SimulationHandler(); h.set_option(_ffi.OPT_TIMING, 1)
     h.add_many(xs, ys, 50, 15)
-    for _ in range(5): h.step()
+    S = int(os.environ.get('EGG_S', '2')); Cc = int(os.environ.get('EGG_C', '3'))
+    for _ in range(5): h.step(1 / 60, S, Cc)
     L = _ffi.load(); L.egg_prof_reset()
     kms = 0
-    for _ in range(steps): h.step(); kms += h.stats()["last_step_kernel_ms"]
+    for _ in range(steps): h.step(1 / 60, S, Cc); kms += h.stats()["last_step_kernel_ms"]
     buf = (C.c_ulonglong * 16)(); L.egg_prof_read(buf)
     calls = buf[11]
     tot = sum(buf[k] for k in range(10))
-    print("batches=%d kernel %.3f ms/step; tile-0 kernels=%d total ticks/kernel=%.0f rounds/kernel=%.0f" % (nb, kms / steps, calls, tot / calls, buf[10] / calls))
+    print("S=%d C=%d" % (S, Cc), "batches=%d kernel %.3f ms/step; tile-0 kernels=%d total ticks/kernel=%.0f rounds/kernel=%.0f" % (nb, kms / steps, calls, tot / calls, buf[10] / calls))
     for k in range(10): print("   %-10s %10.0f ticks/kernel  %5.1f%%" % (names[k], buf[k] / calls, 100.0 * buf[k] / tot))
 if __name__ == "__main__":
     for nb in [int(a) for a in sys.argv[1:]] or [1]: run(nb)

@@ -31,6 +31,8 @@ OPT_CLAIM_MARGIN_CELLS = 0
 OPT_TILE_TARGET_PARTICLES = 1
 OPT_TIMING = 2
 OPT_FORCE_SINGLE_TILE = 3
+OPT_THREADS_PER_PARTICLE = 4
+OPT_SPIN_SLEEP = 5
 
 CONFIG_FIELDS = ["damping", "follow_strength", "cohesion_strength",
                  "cohesion_interaction_distance_factor", "collision_strength",
@@ -76,6 +78,7 @@ _SIGNATURES = {
     "egg_list_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "egg_get_elapsed": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egg_download_particles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "egg_selftest_arith": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
     "egg_get_stats": (C.c_int, [C.c_void_p, C.POINTER(EggStats)]),
     "egg_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
 }

@@ -50,6 +50,7 @@ struct EggStepArgs {
     int32_t ccap;      // cells: dense grid capacity (use_grid) or hash slots (power of two)
     int32_t use_grid;  // 1: cells are a dense grid over the tile's claim box, 0: open-addressing hash
     int32_t lcap;      // visit-list entries per pass (capacity)
+    int32_t spin_sleep;  // 1: idle waves of the pair dataflow sleep between polls (many tiles per CU)
     EggStatus *status;
     unsigned char *scratch;  // egg_step_kernel_gl: n_tiles slices of egg_step_scratch_bytes()
 };
@@ -93,7 +94,7 @@ static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_gr
 }
 
 // threads of the workgroup that runs a tile of at most nmax particles (one thread per particle)
-static inline int egg_step_threads(int nmax) {
-    int t = (nmax + EGG_WAVE - 1) / EGG_WAVE * EGG_WAVE;
+static inline int egg_step_threads(int nmax, int spread) {
+    int t = (nmax * spread + EGG_WAVE - 1) / EGG_WAVE * EGG_WAVE;
     return t < EGG_WAVE ? EGG_WAVE : (t > 1024 ? 1024 : t);
 }

@@ -23,6 +23,7 @@
 
 extern "C" __global__ void egg_step_kernel(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl(EggStepArgs A);
+extern "C" __global__ void egg_selftest_arith_kernel(unsigned long long, int, unsigned long long *);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
                                                    int, double, int32_t *);
 extern "C" __global__ void egg_rederive_kernel(const double *, double *, double *, int, int, double, double, int,
@@ -142,6 +143,8 @@ struct egg_handle {
     int opt_tile_target = 0;
     int opt_timing = 0;
     int opt_force_single = 0;
+    int opt_spread = 1;
+    int opt_spin_sleep = -1;  // -1 auto  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
     hipDeviceProp_t prop{};
     size_t lds_limit = 64 * 1024;  // dynamic LDS a step-kernel workgroup may use
 };
@@ -652,13 +655,15 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.ccap = lc.ccap;
         A.use_grid = lc.use_grid;
         A.lcap = lc.lcap;
+        // more tiles than the chip can hold at one per CU: idle waves yield their issue slots
+        A.spin_sleep = (h->opt_spin_sleep < 0) ? (lc.n_tiles > 2 * h->prop.multiProcessorCount ? 1 : 0) : h->opt_spin_sleep;
         A.status = s.d_status;
         A.scratch = s.d_scratch.p + lc.scratch_offset;
         if (lc.global_lists)
-            hipLaunchKernelGGL(egg_step_kernel_gl, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax)),
+            hipLaunchKernelGGL(egg_step_kernel_gl, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
                                lc.lds, s.stream, A);
         else
-            hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax)),
+            hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
                                lc.lds, s.stream, A);
         HIP_TRY(h, hipGetLastError());
         h->stats.kernel_launches++;
@@ -871,6 +876,11 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
     (void)hipGetDeviceProperties(&h->prop, device);
     h->sys[0].cfg = *white;
     h->sys[1].cfg = yolk ? *yolk : *white;
+    for (int w = 0; w < 2; ++w)
+        if (!(h->sys[w].cfg.eps >= 0x1p-300 && h->sys[w].cfg.eps <= 1.0)) {
+            delete h;
+            return fail(nullptr, EGG_ERR_INVALID_ARGUMENT, "egg_config.eps must be in [2^-300, 1]");
+        }
     // a workgroup gets 64 KiB of dynamic LDS by default; ask for as much of the CU's 160 KiB as the
     // runtime grants for this kernel
     for (size_t want = kLdsMax; want > h->lds_limit; want -= 16 * 1024) {
@@ -927,6 +937,7 @@ void egg_destroy(egg_handle *h) {
 
 int egg_set_config(egg_handle *h, int which, const egg_config *cfg) {
     if (!h || !cfg || (which != EGG_WHITE && which != EGG_YOLK)) return EGG_ERR_INVALID_ARGUMENT;
+    if (!(cfg->eps >= 0x1p-300 && cfg->eps <= 1.0)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_config.eps must be in [2^-300, 1]");
     h->sys[which].cfg = *cfg;
     return EGG_OK;
 }
@@ -1280,6 +1291,24 @@ int egg_download_particles(egg_handle *h, int which, int field, double *dst, int
     return EGG_OK;
 }
 
+int egg_selftest_arith(egg_handle *h, int64_t n_operand_pairs, uint64_t seed, int64_t *mismatches) {
+    if (!h || !mismatches || n_operand_pairs < 0) return EGG_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(h->device);
+    DevBuf<unsigned long long> d;
+    HIP_TRY(h, d.reserve(1, false, h->sys[0].stream));
+    HIP_TRY(h, hipMemsetAsync(d.p, 0, sizeof(unsigned long long), h->sys[0].stream));
+    const int threads = 256, blocks = 1024;
+    int per_thread = (int)((n_operand_pairs + (int64_t)threads * blocks - 1) / ((int64_t)threads * blocks));
+    hipLaunchKernelGGL(egg_selftest_arith_kernel, dim3(blocks), dim3(threads), 0, h->sys[0].stream,
+                       (unsigned long long)seed, per_thread, d.p);
+    HIP_TRY(h, hipGetLastError());
+    unsigned long long bad = 0;
+    HIP_TRY(h, hipMemcpyAsync(&bad, d.p, sizeof bad, hipMemcpyDeviceToHost, h->sys[0].stream));
+    HIP_TRY(h, hipStreamSynchronize(h->sys[0].stream));
+    *mismatches = (int64_t)bad;
+    return EGG_OK;
+}
+
 int egg_get_stats(egg_handle *h, egg_stats *out) {
     if (!h || !out) return EGG_ERR_INVALID_ARGUMENT;
     *out = h->stats;
@@ -1306,6 +1335,13 @@ int egg_set_option(egg_handle *h, int option, double value) {
             h->opt_timing = value != 0;
             h->stats.kernel_ms_sum[0] = h->stats.kernel_ms_sum[1] = 0;
             h->stats.timed_steps = 0;
+            return EGG_OK;
+        case EGG_OPT_THREADS_PER_PARTICLE:
+            if (value != 1 && value != 2 && value != 4) return fail(h, EGG_ERR_INVALID_ARGUMENT, "threads per particle must be 1, 2 or 4");
+            h->opt_spread = (int)value;
+            return EGG_OK;
+        case EGG_OPT_SPIN_SLEEP:
+            h->opt_spin_sleep = value < 0 ? -1 : (value != 0);
             return EGG_OK;
         case EGG_OPT_FORCE_SINGLE_TILE:
             h->opt_force_single = value != 0;

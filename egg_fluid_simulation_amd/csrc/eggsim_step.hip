@@ -143,16 +143,56 @@ __device__ inline uint32_t cell_meta(const Tile &t, int buf, uint32_t key) {
     return 0;
 }
 
+// ---- f64 division and square root without the hardware expansions' scaling steps -----------
+// hipcc expands `n / d` to v_div_scale x2, v_rcp_f64, two FMA Newton steps, q = n * r,
+// rem = fma(-d, q, n), v_div_fmas (= fma(rem, r, q) with scale fix-up), v_div_fixup (special
+// values), and sqrt(x) to an input ldexp, v_rsq_f64, a Goldschmidt iteration, an output ldexp and
+// a class test for 0 / inf.  A lone wave issues one FP64 instruction per ~8 cycles, and the pair
+// projection below sits on the step's critical path, so every instruction counts.  The functions
+// here are the same arithmetic minus the scaling / special-value steps, which are the identity
+// while all operands and results are normal numbers far from the exponent limits.  Inside that
+// window the results are bit-identical to `/` and sqrt() (egg_selftest_arith compares them on
+// random operands on the device); outside it the projection uses the operators.
+__device__ __forceinline__ double egg_rcp_refined(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double egg_div_with_rcp(double n, double d, double r) {
+    double q = n * r;
+    double rem = __builtin_fma(-d, q, n);
+    return __builtin_fma(rem, r, q);
+}
+__device__ __forceinline__ double egg_sqrt_core(double x) {  // valid for x in [2^-600, 2^600]
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return g;
+}
+#define EGG_ARITH_LO 0x1p-300
+#define EGG_ARITH_HI 0x1p300
+
 // XPBD distance projection between two particles, L:1514-1545 with the collision caller
 // L:1632-1654 (and the numerically dead cohesion block L:1603-1630).  pa/pb are the current
 // positions, wra/wrb the (inverse mass, radius) records.  Returns true when pa/pb changed.
 __device__ inline bool project_pair(const Tile &t, int a, int b, double2 &pa, double2 &pb, double2 wra, double2 wrb,
                                     double overlap, double compliance, double eps) {
-    double wa = wra.x, wb = wrb.x;
-    if (wa + wb < eps) return false;  // L:1601
+    const double wa = wra.x, wb = wrb.x;
+    const double wsum = wa + wb;
+    if (wsum < eps) return false;  // L:1601
     bool changed = false;
-    double dx = pb.x - pa.x, dy = pb.y - pa.y;
-    double d2 = dx * dx + dy * dy;
+    const double dx = pb.x - pa.x, dy = pb.y - pa.y;
+    const double d2 = dx * dx + dy * dy;
     if (d2 <= 0.0) {
         if (t.abatch[t.aslot[a]] == t.abatch[t.aslot[b]]) {
             // cohesion fires only for coincident same-batch particles (interaction distance 0,
@@ -163,31 +203,65 @@ __device__ inline bool project_pair(const Tile &t, int a, int b, double2 &pa, do
             changed = true;
         }
     }
-    double min_distance = overlap * (wra.y + wrb.y);
-    if (d2 <= min_distance * min_distance) {
-        double current = sqrt(d2);
-        double nx, ny;
-        if (current < eps) {  // math.normalize, math.lua:53-60
-            nx = 0.0;
-            ny = 0.0;
-        } else {
-            nx = dx / current;
-            ny = dy / current;
+    const double min_distance = overlap * (wra.y + wrb.y);
+    const double md2 = min_distance * min_distance;
+    if (d2 <= md2) {
+        const double divisor = wsum + compliance;
+        // Fast path window.  d2 in [2^-600, 2^600] makes the scaling-free square root exact-equal to
+        // sqrt(); current >= eps (tested anyway for normalize, eps >= 2^-300 is checked by the host)
+        // and current <= 2^300 (from d2) cover the denominator of the normalisation; divisor >= eps is
+        // tested anyway; numerators must be non-zero normal numbers (a zero numerator would lose its
+        // sign in the hand expansion).  NaN fails every comparison.  Bitwise &: one branch.
+        const bool window = ((int)(d2 >= 0x1p-600) & (int)(d2 <= 0x1p600) & (int)(fabs(dx) >= EGG_ARITH_LO) &
+                             (int)(fabs(dy) >= EGG_ARITH_LO) & (int)(divisor <= EGG_ARITH_HI)) != 0;
+        double nx, ny, correction, violation;
+        bool fast = false;
+        if (__builtin_expect(window, 1)) {
+            const double current = egg_sqrt_core(d2);
+            violation = current - min_distance;
+            fast = ((int)(current >= eps) & (int)(divisor >= eps) & (int)(fabs(violation) >= EGG_ARITH_LO)) != 0;
+            if (__builtin_expect(fast, 1)) {
+                const double r_current = egg_rcp_refined(current);
+                const double r_divisor = egg_rcp_refined(divisor);
+                nx = egg_div_with_rcp(dx, current, r_current);
+                ny = egg_div_with_rcp(dy, current, r_current);
+                correction = egg_div_with_rcp(-violation, divisor, r_divisor);
+                // clamp(correction, -|violation|, |violation|): no NaN or signed-zero subtleties here
+                // (|violation| > 0), so min/max are the reference's two comparisons
+                const double max_correction = fabs(violation);
+                correction = fmin(fmax(correction, -max_correction), max_correction);
+            }
         }
-        double violation = current - min_distance;
-        double divisor = (wa + wb) + compliance;
         double cax, cay, cbx, cby;
-        if (divisor < eps) {
-            cax = cay = cbx = cby = 0.0;
+        if (!fast) {  // the reference's expressions, operator by operator
+            const double current = sqrt(d2);
+            violation = current - min_distance;
+            if (current < eps) {  // math.normalize, math.lua:53-60
+                nx = 0.0;
+                ny = 0.0;
+            } else {
+                nx = dx / current;
+                ny = dy / current;
+            }
+            if (divisor < eps) {
+                cax = cay = cbx = cby = 0.0;
+            } else {
+                correction = -violation / divisor;
+                const double max_correction = fabs(violation);
+                if (correction < -max_correction) correction = -max_correction;
+                if (correction > max_correction) correction = max_correction;
+                cax = -nx * correction * wa;
+                cay = -ny * correction * wa;
+                cbx = nx * correction * wb;
+                cby = ny * correction * wb;
+            }
         } else {
-            double correction = -violation / divisor;
-            double max_correction = fabs(violation);
-            if (correction < -max_correction) correction = -max_correction;
-            if (correction > max_correction) correction = max_correction;
-            cax = -nx * correction * wa;
-            cay = -ny * correction * wa;
-            cbx = nx * correction * wb;
-            cby = ny * correction * wb;
+            // -nx * correction == -(nx * correction) bit for bit (rounding is sign-symmetric)
+            const double tx = nx * correction, ty = ny * correction;
+            cax = -tx * wa;
+            cay = -ty * wa;
+            cbx = tx * wb;
+            cby = ty * wb;
         }
         pa.x = pa.x + cax;
         pa.y = pa.y + cay;
@@ -210,6 +284,8 @@ struct PassCtx {
 
 // fresh pass (hash and collided were cleared): adjacency is symmetric, the smaller index visits,
 // so own(i) = { j > i in the 3x3 cells }, cells in loop order, ascending j inside a cell.
+// FILL also counts, per partner, how many selves visit it (t.done doubles as that counter until
+// the pair scheduler starts): the transposition below needs it and the atomic needs no return.
 template <bool FILL>
 __device__ inline int enum_fresh(const Tile &t, int cur, int i, uint16_t *dst) {
     const uint32_t ki = t.ckey(cur)[i];
@@ -231,13 +307,19 @@ __device__ inline int enum_fresh(const Tile &t, int cur, int i, uint16_t *dst) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (q < cn && (int)it[s][q] > i) {
-                if (FILL) dst[count] = it[s][q];
+                if (FILL) {
+                    dst[count] = it[s][q];
+                    atomicAdd(&t.done[it[s][q]], 1u);
+                }
                 ++count;
             }
         for (int e = 4; e < cn; ++e) {
             int j = items[st + e];
             if (j > i) {
-                if (FILL) dst[count] = (uint16_t)j;
+                if (FILL) {
+                    dst[count] = (uint16_t)j;
+                    atomicAdd(&t.done[j], 1u);
+                }
                 ++count;
             }
         }
@@ -303,7 +385,10 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint16_
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (e0 + q < cn && accept_stale(t, c, i, j[q], s, isnew, kni, koi, knj[q], koj[q])) {
-                        if (FILL) dst[count] = (uint16_t)j[q];
+                        if (FILL) {
+                            dst[count] = (uint16_t)j[q];
+                            atomicAdd(&t.done[j[q]], 1u);
+                        }
                         ++count;
                     }
             }
@@ -328,7 +413,8 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint16_
 #define EGG_COMPILER_BARRIER() __asm__ volatile("" ::: "memory")
 
 __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, int nthreads, double overlap,
-                                       double compliance, double eps, int total, unsigned int &spins_out) {
+                                       double compliance, double eps, int total, int spin_sleep,
+                                       unsigned int &spins_out) {
     uint32_t *done = t.done;
     int solved = 0;
     unsigned int spins = 0;
@@ -337,10 +423,14 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
     // a topological order of the dependencies, so a pair only ever waits for pairs of selves <= its
     // own self, and those belong to the same or an earlier slice [base * nthreads, ...) which
     // every thread finishes first.
-    const int per = (n + nthreads - 1) / nthreads;
+    // Particles can be spread over more threads (thread = particle * spread, EGG_OPT_THREADS_PER_PARTICLE);
+    // measured: no gain in latency, a loss in throughput, so the default is 1.
+    const int spread = (nthreads >= 4 * n) ? 4 : (nthreads >= 2 * n) ? 2 : 1;
+    const int slots = nthreads / spread;
+    const int per = (n + slots - 1) / slots;
     const unsigned int cap = 16u * (unsigned int)(total + 8) + 4096u;
     for (int base = 0; base < per; ++base) {
-        const int a = tid + base * nthreads;
+        const int a = (tid % spread == 0) ? tid / spread + base * slots : n;
         const bool has = a < n;
         const int as = has ? a : 0;
         const int o0 = has ? (int)t.own_off(cur)[a] : 0;
@@ -378,7 +468,9 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
                 ent = ent_next;
                 ++solved;
             }
-            if (!__any(ready)) __builtin_amdgcn_s_sleep(1);
+            // a wave with nothing ready only burns issue slots its SIMD neighbours could use; park it
+            // briefly when several tiles share the CU (costs ~3 % when a tile has the CU to itself)
+            if (spin_sleep && !__any(ready)) __builtin_amdgcn_s_sleep(2);
             if (++spins > cap) break;  // cannot happen; guards against a hang
         }
     }
@@ -700,7 +792,13 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                     __syncthreads();
                     for (int i = tid; i <= n; i += nthreads)
                         t.own_off(cur)[i] = min(t.own_off(cur)[i], (uint32_t)cut_pos);
+                    for (int i = tid; i < n; i += nthreads) t.done[i] = 0;
                     total = (int)cut_pos;
+                    __syncthreads();
+                    // the incoming counts gathered while filling included the entries just cut off
+                    for (int i = tid; i < n; i += nthreads)
+                        for (uint32_t e = t.own_off(cur)[i]; e < t.own_off(cur)[i + 1]; ++e)
+                            atomicAdd(&t.done[t.own_ent(cur)[e]], 1u);
                     __syncthreads();
                 }
             }
@@ -712,22 +810,33 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             PROF(5)  // budget
             // ---- ranks: transpose the visit lists (incoming pairs per particle), rank every incoming
             //      pair inside its particle's sequence, and store the rank next to the visit entry
+            // t.done holds the incoming-pair count of every particle (gathered by the fill pass)
+            wave0_exclusive_scan(t.done, t.inc_off, n, tid);
             for (int i = tid; i < n; i += nthreads) t.fill[i] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += nthreads)
-                for (uint32_t e = t.own_off(cur)[i]; e < t.own_off(cur)[i + 1]; ++e)
-                    atomicAdd(&t.fill[t.own_ent(cur)[e]], 1u);
-            __syncthreads();
-            wave0_exclusive_scan(t.fill, t.inc_off, n, tid);
-            __syncthreads();
-            for (int i = tid; i < n; i += nthreads) t.fill[i] = 0;
-            __syncthreads();
-            for (int i = tid; i < n; i += nthreads)
-                for (uint32_t e = t.own_off(cur)[i]; e < t.own_off(cur)[i + 1]; ++e) {
+            for (int i = tid; i < n; i += nthreads) {
+                t.done[i] = 0;  // from here on: the scheduler's progress counter
+                const uint32_t e0 = t.own_off(cur)[i], e1 = t.own_off(cur)[i + 1];
+                uint32_t e = e0;
+                for (; e + 4 <= e1; e += 4) {  // four independent chains in flight
+                    int j[4];
+                    uint32_t pos[4], base[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) j[q] = t.own_ent(cur)[e + q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        pos[q] = atomicAdd(&t.fill[j[q]], 1u);
+                        base[q] = t.inc_off[j[q]];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t.inc_tmp[base[q] + pos[q]] = (uint32_t)i | ((e + q) << 16);
+                }
+                for (; e < e1; ++e) {
                     int j = t.own_ent(cur)[e];
                     uint32_t pos = atomicAdd(&t.fill[j], 1u);
                     t.inc_tmp[t.inc_off[j] + pos] = (uint32_t)i | (e << 16);
                 }
+            }
             __syncthreads();
             for (int i = tid; i < n; i += nthreads) {
                 const int st = (int)t.inc_off[i], cn = (int)t.inc_off[i + 1] - st;
@@ -751,7 +860,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             // -------------------------------------- dataflow execution of the pair projections
             unsigned int spins = 0;
             int solved = execute_dataflow(t, cur, n, tid, nthreads, A.overlap_factor, A.collision_compliance, eps,
-                                          total, spins);
+                                          total, A.spin_sleep, spins);
             spins_total += spins;
             __syncthreads();
             PROF(7)  // DAG
@@ -860,6 +969,58 @@ extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel(EggStepArgs A
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true>(A); }
 
 #ifdef EGG_PROFILE
+// developer microbenchmark (diagnostic build only): cycles per dependent projection of one wave,
+// operands in registers (mode 0), or through LDS like the dataflow loop (mode 1)
+extern "C" __global__ void egg_microbench_kernel(int mode, int iters, int active_lanes, unsigned long long *out) {
+    __shared__ double2 lpos[128];
+    __shared__ double2 lwr[128];
+    __shared__ int lbatch[2];
+    __shared__ uint16_t lslot[128];
+    Tile t;
+    t.abatch = lbatch;
+    t.aslot = lslot;
+    const int lane = threadIdx.x;
+    lpos[lane] = make_double2(10.0 + lane * 0.37, 5.0 + lane * 0.11);
+    lpos[lane + 64] = make_double2(17.0 + lane * 0.35, 9.0 + lane * 0.13);
+    lwr[lane] = make_double2(0.7 + 0.001 * lane, 4.0);
+    lwr[lane + 64] = make_double2(0.8, 4.0);
+    lslot[lane] = 0;
+    lslot[lane + 64] = 0;
+    if (lane < 2) lbatch[lane] = lane;
+    __syncthreads();
+    double2 pa = lpos[lane], pb = lpos[lane + 64];
+    const double2 wra = lwr[lane], wrb = lwr[lane + 64];
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (lane < active_lanes) {
+        for (int i = 0; i < iters; ++i) {
+            if (mode == 1) {
+                pa = lpos[lane];
+                pb = lpos[lane + 64];
+            }
+            project_pair(t, lane, lane + 64, pa, pb, wra, wrb, 2.0, 36.0, 1e-8);
+            if (mode == 1) {
+                lpos[lane] = pa;
+                lpos[lane + 64] = pb;
+            }
+            // keep the pair in range so that every iteration takes the full path
+            pb.x = pb.x - 0.9 * (pb.x - pa.x) * 0.01;
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        out[0] = t1 - t0;
+        out[1] = (unsigned long long)__double_as_longlong(pa.x + pb.y);
+    }
+}
+extern "C" void egg_microbench(int mode, int iters, int active_lanes, unsigned long long *cycles) {
+    unsigned long long *d = nullptr;
+    (void)hipMalloc((void **)&d, 16);
+    hipLaunchKernelGGL(egg_microbench_kernel, dim3(1), dim3(64), 0, 0, mode, iters, active_lanes, d);
+    unsigned long long h[2] = {0, 0};
+    (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    *cycles = h[0];
+}
 extern "C" void egg_prof_read(unsigned long long *out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(egg_prof), sizeof(egg_prof));
 }
@@ -868,6 +1029,42 @@ extern "C" void egg_prof_reset() {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(egg_prof), z, sizeof(z));
 }
 #endif
+
+// ---------------------------------------------------------------------------
+// self test of the scaling-free division and square root: mismatches against `/` and sqrt() on
+// random operands drawn across their windows (counter-based xorshift per thread)
+extern "C" __global__ void egg_selftest_arith_kernel(unsigned long long seed, int per_thread,
+                                                      unsigned long long *mismatches) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x + 1);
+    unsigned long long bad = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        unsigned long long v[2];
+        for (int q = 0; q < 2; ++q) {
+            z ^= z << 13;
+            z ^= z >> 7;
+            z ^= z << 17;
+            unsigned long long mant = z & 0xFFFFFFFFFFFFFull;
+            z ^= z << 13;
+            z ^= z >> 7;
+            z ^= z << 17;
+            // exponents: mostly the solver's range (2^-40 .. 2^20), sometimes the whole window
+            unsigned long long e = (k & 7) ? 1023ull - 40ull + (z >> 11) % 61ull : 723ull + (z >> 11) % 601ull;
+            unsigned long long sign = (z >> 5) & 1ull;
+            v[q] = (sign << 63) | (e << 52) | mant;
+        }
+        double n = __longlong_as_double((long long)v[0]), d = __longlong_as_double((long long)v[1]);
+        double want = n / d;
+        double got = egg_div_with_rcp(n, d, egg_rcp_refined(d));
+        if (__double_as_longlong(want) != __double_as_longlong(got)) ++bad;
+        // square root: |n| spans [2^-300, 2^300]; its square (up to rounding) spans the sqrt window
+        double x = (k & 1) ? fabs(n) : n * n;
+        if (x >= 0x1p-600 && x <= 0x1p600) {
+            double ws = sqrt(x), gs = egg_sqrt_core(x);
+            if (__double_as_longlong(ws) != __double_as_longlong(gs)) ++bad;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 
 // ---------------------------------------------------------------------------
 // small kernels around the step

@@ -390,5 +390,11 @@ class SimulationHandler:
                     last_step_kernel_ms=s.last_step_kernel_ms, single_tile=list(s.single_tile),
                     kernel_ms=list(s.kernel_ms), kernel_ms_sum=list(s.kernel_ms_sum), timed_steps=s.timed_steps)
 
+    def selftest_arith(self, n=1 << 24, seed=1):
+        """mismatches of the kernel's hand-expanded f64 division against `/` on n random operand pairs"""
+        bad = C.c_int64()
+        self._check(self._lib.egg_selftest_arith(self._h, int(n), int(seed), C.byref(bad)))
+        return bad.value
+
     def set_option(self, option, value):
         self._check(self._lib.egg_set_option(self._h, int(option), float(value)))

@@ -149,12 +149,19 @@ typedef struct {
 } egg_stats;
 int egg_get_stats(egg_handle *h, egg_stats *out);
 
+/* Diagnostic: the step kernel expands its f64 divisions and square root by hand (see
+ * eggsim_step.hip); this runs those expansions against `/` and sqrt() on n random operand pairs on
+ * the device and returns the number of results that differ in any bit (must be 0). */
+int egg_selftest_arith(egg_handle *h, int64_t n_operand_pairs, uint64_t seed, int64_t *mismatches);
+
 /* tuning knobs (not part of the reference surface) */
 enum {
     EGG_OPT_CLAIM_MARGIN_CELLS = 0, /* initial margin around an atom's cells when tiles are formed */
     EGG_OPT_TILE_TARGET_PARTICLES,  /* pack independent islands into tiles up to this size (0 = one island per tile) */
     EGG_OPT_TIMING,                 /* 1: record HIP events around the step kernels */
-    EGG_OPT_FORCE_SINGLE_TILE       /* 1: always run each type as one tile (exact budget path) */
+    EGG_OPT_FORCE_SINGLE_TILE,      /* 1: always run each type as one tile (exact budget path) */
+    EGG_OPT_THREADS_PER_PARTICLE,   /* 1, 2 or 4: spread a tile's particles over more waves (latency vs occupancy) */
+    EGG_OPT_SPIN_SLEEP              /* -1 auto, 0 never, 1 always: idle dataflow waves sleep between polls */
 };
 int egg_set_option(egg_handle *h, int option, double value);
 

@@ -24,6 +24,7 @@ def run(nb, steps=20):
     calls = buf[11]
     tot = sum(buf[k] for k in range(10))
     print("S=%d C=%d" % (S, Cc), "batches=%d kernel %.3f ms/step; tile-0 kernels=%d total ticks/kernel=%.0f rounds/kernel=%.0f" % (nb, kms / steps, calls, tot / calls, buf[10] / calls))
+    print("   dataflow loop of wave 0: load-wait %.0f ticks/kernel, solve+store %.0f, busy iterations %.0f, idle iterations %.0f" % (buf[12] / calls, buf[13] / calls, buf[14] / calls, buf[15] / calls))
     for k in range(10): print("   %-10s %10.0f ticks/kernel  %5.1f%%" % (names[k], buf[k] / calls, 100.0 * buf[k] / tot))
 if __name__ == "__main__":
     for nb in [int(a) for a in sys.argv[1:]] or [1]: run(nb)

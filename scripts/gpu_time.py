@@ -10,6 +10,9 @@ def run(nb, steps=50, warm=10, pack=0):
     h = SimulationHandler()
     h.set_option(_ffi.OPT_TIMING, 1)
     if pack: h.set_option(_ffi.OPT_TILE_TARGET_PARTICLES, pack)
+    sp = int(os.environ.get('EGG_SPREAD', '1'))
+    if sp != 1: h.set_option(_ffi.OPT_THREADS_PER_PARTICLE, sp)
+    if 'EGG_SLEEP' in os.environ: h.set_option(_ffi.OPT_SPIN_SLEEP, int(os.environ['EGG_SLEEP']))
     h.add_many(xs, ys, 50, 15)
     for _ in range(warm): h.step()
     t0 = time.perf_counter(); kms = 0.0

@@ -171,6 +171,13 @@ def test_batches_that_merge_and_separate(egg, oracle_mod):
     assert tiles[0] == 2 and min(tiles) == 1
 
 
+def test_hand_expanded_division_is_bit_identical_to_operator(egg):
+    """the projection's VCC-free division must equal `/` for every operand pair in its window"""
+    h = egg.SimulationHandler()
+    for seed in (1, 2, 3):
+        assert h.selftest_arith(1 << 26, seed) == 0  # 3 x 67M random operand pairs
+
+
 def test_sqrt_and_division_are_correctly_rounded_on_device(egg, oracle_mod):
     """the parity argument needs IEEE sqrt and division in the kernel; a follow-only run exercises
     exactly one sqrt, two normalising divisions and one lambda division per particle"""

@@ -66,30 +66,32 @@ __host__ __device__
 #endif
 static inline size_t egg_step_scratch_bytes(int lcap, int single_tile) {
     size_t l = (size_t)lcap;
-    return 2 * ((l * 4 + 15) & ~(size_t)15) + ((((single_tile ? 2 : 1) * l * 2) + 15) & ~(size_t)15);
+    return 2 * ((l * 4 + 15) & ~(size_t)15) + ((((single_tile ? 2 : 0) * l * 2) + 15) & ~(size_t)15);
 }
 
 // dynamic LDS bytes the step kernel carves for the geometry above (must match eggsim_step.hip)
 static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_grid, int lcap, int single_tile,
-                                        int global_lists) {
+                                        int global_lists, int threads) {
     size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, l = (size_t)lcap;
     size_t b = 0;
-    b += 4 * egg_align16(n * 16);            // pos wr prev vel
+    b += 2 * egg_align16(n * 16);            // pos wr
+    b += 2 * egg_align16(nmax > threads ? n * 16 : 0);  // prev vel (registers otherwise)
     b += 3 * egg_align16(a * 8);             // atx aty afd
     b += egg_align16(2 * n * 4);             // ckey[2]
     b += egg_align16(2 * c * 4);             // cell[2]
     b += egg_align16(use_grid ? 0 : 2 * c * 4);  // hkeys[2]
-    b += egg_align16(2 * (n + 1) * 4);       // own_off[2]
+    b += egg_align16((single_tile ? 2 : 1) * (n + 1) * 4);  // own_off
     b += egg_align16((n + 1) * 4);           // inc_off
     b += 2 * egg_align16(n * 4);             // fill done
     if (!global_lists) b += 2 * egg_align16(l * 4);  // own_pack inc_tmp
     b += egg_align16(a * 4 * 4);             // aclaim
     b += egg_align16((a + 1) * 4);           // aoff
-    b += egg_align16(a * 4);                 // abatch
+    b += 2 * egg_align16(a * 4);             // abatch aglob
+    b += egg_align16(a * 4 * 4);             // aaabb
     b += egg_align16(16 * 4);                // scalars
     b += egg_align16(2 * n * 2);             // hitems[2]
     b += 3 * egg_align16(n * 2);             // pslot aslot nlo
-    if (!global_lists) b += egg_align16((single_tile ? 2 : 1) * l * 2);  // own_ent
+    if (!global_lists) b += egg_align16(single_tile ? 2 * l * 2 : 0);  // own_ent (exact-budget mode)
     return b;
 }
 

@@ -23,6 +23,7 @@
 
 extern "C" __global__ void egg_step_kernel(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl(EggStepArgs A);
+extern "C" __global__ void egg_step_kernel_occ(EggStepArgs A);
 extern "C" __global__ void egg_selftest_arith_kernel(unsigned long long, int, unsigned long long *);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
                                                    int, double, int32_t *);
@@ -549,14 +550,16 @@ int retile(egg_handle *h, int which) {
         lcap = std::min<size_t>(lcap, kMaxListEntries);
         lcap = (lcap + 7) & ~(size_t)7;
         lc.lcap = (int)lcap;
-        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0);
-        if (lc.lds > h->lds_limit || lc.lds > 96 * 1024) {
+        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0,
+                                    egg_step_threads(lc.nmax, h->opt_spread));
+        if (lc.lds > h->lds_limit || lc.lds > 64 * 1024 || egg_step_threads(lc.nmax, h->opt_spread) > 256) {
             // dense or large tiles: particle state stays in LDS, the visit lists go to global memory
             lc.global_lists = 1;
             lcap = std::max<size_t>({lcap, (size_t)(32.0 * lc.nmax), s.list_min});
             lcap = std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxListEntries);
             lc.lcap = (int)lcap;
-            lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1);
+            lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1,
+                                        egg_step_threads(lc.nmax, h->opt_spread));
             lc.scratch_offset = scratch_bytes;
             scratch_bytes += (size_t)lc.n_tiles * egg_step_scratch_bytes(lc.lcap, single ? 1 : 0);
         }
@@ -662,6 +665,9 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         if (lc.global_lists)
             hipLaunchKernelGGL(egg_step_kernel_gl, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
                                lc.lds, s.stream, A);
+        else if (lc.n_tiles >= 4 * h->prop.multiProcessorCount)  // throughput regime: residency over spill-freedom
+            hipLaunchKernelGGL(egg_step_kernel_occ, dim3((unsigned)lc.n_tiles),
+                               dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)), lc.lds, s.stream, A);
         else
             hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
                                lc.lds, s.stream, A);
@@ -887,6 +893,8 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
         e = hipFuncSetAttribute((const void *)egg_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)egg_step_kernel_gl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess) {
             h->lds_limit = want;
             break;

@@ -34,6 +34,8 @@ struct EggStepArgs {
     const double *atom_fd;            // 2 * sqrt(batch radius) (L:1454, L:1790)
     const int32_t *atom_claim;   // int4 {lo_x, lo_y, hi_x, hi_y}: cells the atom's particles may occupy this step
     int32_t *atom_aabb_out;      // int4: cells occupied at the end of the step
+    int32_t *atom_fail;          // set to 1 when a particle of the atom left its claim
+    int32_t *atom_disp_out;      // int4: max particle travel in the LAST sub-step towards +x, -x, +y, -y (1/16 px)
     // tiles: independent groups of atoms, one workgroup each
     const int32_t *tile_atom_begin;  // [n_tiles + 1] into tile_atoms
     const int32_t *tile_atoms;       // atom ids, ascending inside a tile
@@ -87,7 +89,7 @@ static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_gr
     b += egg_align16(a * 4 * 4);             // aclaim
     b += egg_align16((a + 1) * 4);           // aoff
     b += 2 * egg_align16(a * 4);             // abatch aglob
-    b += egg_align16(a * 4 * 4);             // aaabb
+    b += 2 * egg_align16(a * 4 * 4);         // aaabb adisp
     b += egg_align16(16 * 4);                // scalars
     b += egg_align16(2 * n * 2);             // hitems[2]
     b += 3 * egg_align16(n * 2);             // pslot aslot nlo

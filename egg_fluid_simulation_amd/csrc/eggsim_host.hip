@@ -110,6 +110,13 @@ struct System {  // one particle type
     bool aabb_valid = false;
     bool aabb_on_device = false;  // d_atom_aabb holds the cells of the CURRENT positions (written by the last step)
     bool atoms_dirty = true, targets_dirty = true, tiling_dirty = true;
+    bool claims_stale = false;  // a target moved since the tiles were formed
+    std::vector<int32_t> disp;                  // per atom: max particle travel of the last step (+x,-x,+y,-y; 1/16 px)
+    bool disp_valid = false;                    // fetched together with the boxes of the current positions
+    DevBuf<int32_t> d_atom_disp;
+    bool swept = false;                          // some claim was extended along predicted motion
+    std::vector<int> extra_margin;               // per batch: extra claim cells after a failed check (decays)
+    DevBuf<int32_t> d_atom_fail;                 // per atom: a particle left the claim in the last launch
     // tiles
     std::vector<int32_t> tile_atom_begin, tile_atoms;
     DevBuf<int32_t> d_tile_atom_begin, d_tile_atoms;
@@ -124,6 +131,9 @@ struct System {  // one particle type
     bool has_env = false;
     double env_min_mass = 0, env_max_mass = 0, env_min_radius = 0, env_max_radius = 0;
     double tiled_cell_size = 0;
+    // parameters of the step the tiles are being formed for (claims are swept along the follow motion)
+    double step_follow_compliance = 57.6, step_damping = 0.9;
+    int step_substeps = 2;
     EggStatus *d_status = nullptr;
     EggStatus *h_status = nullptr;  // pinned
     hipStream_t stream = nullptr;
@@ -307,6 +317,8 @@ int upload_atoms(egg_handle *h, int which) {
         HIP_TRY(h, s.d_atom_batch.reserve(na + 1, false, s.stream));
         HIP_TRY(h, s.d_atom_claim.reserve(4 * na + 4, false, s.stream));
         HIP_TRY(h, s.d_atom_aabb.reserve(4 * na + 4, false, s.stream));
+        HIP_TRY(h, s.d_atom_fail.reserve(na + 1, false, s.stream));
+        HIP_TRY(h, s.d_atom_disp.reserve(4 * na + 4, false, s.stream));
         HIP_TRY(h, s.d_atom_tx.reserve(na + 1, false, s.stream));
         HIP_TRY(h, s.d_atom_ty.reserve(na + 1, false, s.stream));
         HIP_TRY(h, s.d_atom_fd.reserve(na + 1, false, s.stream));
@@ -318,6 +330,7 @@ int upload_atoms(egg_handle *h, int which) {
         s.atoms_dirty = false;
         s.targets_dirty = true;
         s.tiling_dirty = true;
+        s.disp_valid = false;
         s.aabb_valid = s.aabb_on_device = false;
     }
     if (s.targets_dirty) {
@@ -362,6 +375,7 @@ int retile(egg_handle *h, int which) {
     if (rc != EGG_OK) return rc;
     const size_t na = s.atoms.size();
     const double cell = cell_size_of(s.cfg);
+    s.extra_margin.resize(h->batches.size(), 0);
     s.tile_atom_begin.assign(1, 0);
     s.tile_atoms.clear();
     s.classes.clear();
@@ -385,6 +399,7 @@ int retile(egg_handle *h, int which) {
         HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), s.d_atom_aabb.p, na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(h, hipStreamSynchronize(s.stream));
         s.aabb_valid = true;
+        s.disp_valid = false;
         h->stats.kernel_launches++;
     }
     for (const Box &b : s.aabb)
@@ -413,9 +428,52 @@ int retile(egg_handle *h, int which) {
             comp[k] = 0;
         }
     } else {
+        // Claim = occupied cells + margin, swept along the displacement the follow constraint is about
+        // to cause: per sub-step a particle farther than the slack from its target moves towards it by
+        // (d - slack) * w / (w + follow compliance) (L:1461-1468), so a blob far from its target moves
+        // many cells in one step in a known direction.  Sweeping the claim that way (with 50 % head room)
+        // keeps fast blobs inside their claims without widening every neighbour's margin.
         const int m = s.margin;
-        for (size_t k = 0; k < na; ++k)
-            claim[k] = Box{s.aabb[k].lo_x - m, s.aabb[k].lo_y - m, s.aabb[k].hi_x + m, s.aabb[k].hi_y + m};
+        const double w_max = 1.0 / std::max(s.cfg.min_mass, 1e-300);  // lightest particle moves most
+        const double pull = w_max / (w_max + s.step_follow_compliance);
+        // inertia: x += dt * v carries on what the particles did in the previous step (times the
+        // damping); the step kernel reports every atom's largest particle travel per direction
+        const bool have_motion = s.disp_valid && s.disp.size() == 4 * na;
+        s.swept = false;
+        for (size_t k = 0; k < na; ++k) {
+            const Box &b = s.aabb[k];
+            const Batch &B = h->batches[(size_t)s.atoms[k].batch];
+            const double cx = 0.5 * ((double)b.lo_x + b.hi_x + 1.0) * cell, cy = 0.5 * ((double)b.lo_y + b.hi_y + 1.0) * cell;
+            const double dx = B.target_x - cx, dy = B.target_y - cy;
+            const double dist = std::sqrt(dx * dx + dy * dy);
+            const double slack = 2 * std::sqrt(which == EGG_WHITE ? B.white_radius : B.yolk_radius);
+            // Predict the step like the solver runs it: per sub-step the displacement is
+            // damping * (previous sub-step's displacement) [pre-solve, L:1411-1418] plus the follow pull
+            // (remaining distance beyond the slack) * w / (w + compliance) [L:1461-1468], along the
+            // direction to the target.  Collisions only redistribute that inside the blob.
+            const double ux = dist > 0 ? dx / dist : 0, uy = dist > 0 ? dy / dist : 0;
+            const int mk = m + s.extra_margin[(size_t)s.atoms[k].batch];
+            int side[4];
+            for (int q = 0; q < 4; ++q) {
+                const double dir = (q == 0) ? ux : (q == 1) ? -ux : (q == 2) ? uy : -uy;  // +x, -x, +y, -y
+                double d = have_motion ? s.disp[4 * k + q] / 16.0 : 0.0;  // last sub-step, towards this side
+                double remaining = (dist > slack && std::isfinite(dist)) ? dist - slack : 0.0;
+                double travel = 0;
+                for (int sub = 0; sub < s.step_substeps; ++sub) {
+                    const double p = remaining * pull;
+                    remaining -= p;
+                    d = s.step_damping * d + std::max(0.0, dir) * p;
+                    travel += d;
+                }
+                side[q] = std::max(mk, (int)std::min(4096.0, std::ceil(1.25 * travel / cell)));
+                s.swept |= side[q] > mk;
+            }
+            claim[k] = Box{b.lo_x - side[1], b.lo_y - side[3], b.hi_x + side[0], b.hi_y + side[2]};
+            static const bool debug_claims = getenv("EGG_DEBUG_CLAIMS") != nullptr;
+            if (debug_claims && k == 0)
+                fprintf(stderr, "[claims] type %d step %lld atom0: dist %.1f obs %d sides +x %d -x %d +y %d -y %d\n", which,
+                        (long long)h->stats.steps, dist, (int)have_motion, side[0], side[1], side[2], side[3]);
+        }
         // union-find over atoms; candidate pairs by a sweep over lo_x
         std::vector<int> parent(na);
         std::iota(parent.begin(), parent.end(), 0);
@@ -616,6 +674,7 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     *s.h_status = init;
     s.aabb_on_device = false;  // the launch overwrites d_atom_aabb
     HIP_TRY(h, hipMemcpyAsync(s.d_status, s.h_status, sizeof(EggStatus), hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(h, hipMemsetAsync(s.d_atom_fail.p, 0, (s.atoms.size() + 1) * sizeof(int32_t), s.stream));
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev0, s.stream));
     for (const LaunchClass &lc : s.classes) {
         EggStepArgs A;
@@ -639,6 +698,8 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.atom_fd = s.d_atom_fd.p;
         A.atom_claim = s.d_atom_claim.p;
         A.atom_aabb_out = s.d_atom_aabb.p;
+        A.atom_fail = s.d_atom_fail.p;
+        A.atom_disp_out = s.d_atom_disp.p;
         A.tile_atom_begin = s.d_tile_atom_begin.p + lc.first_tile;
         A.tile_atoms = s.d_tile_atoms.p;
         A.n_tiles = lc.n_tiles;
@@ -709,6 +770,9 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
             s.tiling_dirty = true;
             s.aabb_valid = false;
         }
+        s.step_follow_compliance = env[w].follow_c;
+        s.step_damping = env[w].damping;
+        s.step_substeps = S;
     }
 
     for (int attempt = 0;; ++attempt) {
@@ -717,6 +781,25 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
             System &s = h->sys[w];
             int rc = upload_atoms(h, w);
             if (rc != EGG_OK) return rc;
+            if (s.claims_stale && !s.tiling_dirty) {
+                // a moved target only matters when some blob is now farther from its target than its
+                // slack + what the margin absorbs; cheap test on the host copy of the boxes
+                if (!s.aabb_valid) {
+                    s.tiling_dirty = true;
+                } else {
+                    const double cell = cell_size_of(s.cfg);
+                    for (size_t k = 0; k < s.atoms.size() && !s.tiling_dirty; ++k) {
+                        const Box &b = s.aabb[k];
+                        const Batch &B = h->batches[(size_t)s.atoms[k].batch];
+                        const double cx = 0.5 * ((double)b.lo_x + b.hi_x + 1.0) * cell;
+                        const double cy = 0.5 * ((double)b.lo_y + b.hi_y + 1.0) * cell;
+                        const double dist = std::hypot(B.target_x - cx, B.target_y - cy);
+                        const double reach = 0.5 * cell * std::max(b.hi_x - b.lo_x, b.hi_y - b.lo_y) + 2 * cell * s.margin;
+                        if (!(dist <= reach + 64.0)) s.tiling_dirty = true;
+                    }
+                }
+            }
+            s.claims_stale = false;
             if (s.tiling_dirty) {
                 rc = retile(h, w);
                 if (rc != EGG_OK) return rc;
@@ -752,8 +835,23 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
             }
             if (st.fail_claim || st.fail_range) {
                 // a particle left its claimed cells: tiles were not provably independent.  Widen the
-                // claims a little (wide claims merge neighbours into one tile) and re-run the step.
-                s.margin = std::min(s.margin + std::max(2, s.margin / 2), 4096);
+                // claims of the atoms it happened to (wide claims merge neighbours into one tile, so
+                // only theirs) and re-run the step.
+                std::vector<int32_t> failed(s.atoms.size());
+                if (!failed.empty()) {
+                    HIP_TRY(h, hipMemcpyAsync(failed.data(), s.d_atom_fail.p, failed.size() * sizeof(int32_t),
+                                              hipMemcpyDeviceToHost, s.stream));
+                    HIP_TRY(h, hipStreamSynchronize(s.stream));
+                }
+                s.extra_margin.resize(h->batches.size(), 0);
+                bool any = false;
+                for (size_t k = 0; k < failed.size(); ++k)
+                    if (failed[k]) {
+                        int &e = s.extra_margin[(size_t)s.atoms[k].batch];
+                        e = std::min(4096, std::max(2, 2 * e));
+                        any = true;
+                    }
+                if (!any) s.margin = std::min(s.margin + std::max(2, s.margin / 2), 4096);  // range failure
                 s.tiling_dirty = true;
                 s.aabb_valid = false;
                 redo = true;
@@ -790,15 +888,22 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
             for (int p = 0; p < np; ++p) h->stats.pair_solves += (int64_t)st.visits[p];
             h->stats.follow_solves += s.n * S;
             s.aabb_valid = false;  // d_atom_aabb now holds end-of-step cells; fetched on demand
+            s.disp_valid = false;
             s.aabb_on_device = true;
-            if (st.min_slack < s.margin) {
-                // some particle has used part of its margin: re-tile around the new positions
+            if (st.min_slack < s.margin || s.swept) {
+                // some particle has used part of its margin, or blobs are flying: re-tile around the
+                // new positions
                 s.tiling_dirty = true;
             }
             if (s.margin > h->opt_margin) {  // widened after a failed check: relax again
                 s.margin -= 1;
                 s.tiling_dirty = true;
             }
+            for (int &e : s.extra_margin)
+                if (e > 0) {
+                    e -= 1;
+                    s.tiling_dirty = true;
+                }
             if (s.single_tile && !h->opt_force_single) {
                 // leave exact mode once the budget has not cut for a while and cannot bind by size
                 s.uncut_streak = st.was_cut ? 0 : s.uncut_streak + 1;
@@ -823,11 +928,14 @@ int fetch_end_aabb(egg_handle *h, System &s) {
     // after a committed step d_atom_aabb holds the atoms' cells at the new positions
     const size_t na = s.atoms.size();
     s.aabb.resize(na);
+    s.disp.resize(4 * na);
     if (na) {
         HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), s.d_atom_aabb.p, na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipMemcpyAsync(s.disp.data(), s.d_atom_disp.p, 4 * na * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(h, hipStreamSynchronize(s.stream));
     }
     s.aabb_valid = true;
+    s.disp_valid = true;  // both describe the step that produced the current positions
     return EGG_OK;
 }
 
@@ -1062,9 +1170,15 @@ int egg_set_target(egg_handle *h, int64_t id, double x, double y) {  // L:254-26
     if (!b)
         return fail(h, EGG_WARN_UNKNOWN_ID, "In SimulationHandler.set_target_position: no batch with id `%lld`",
                     (long long)id);
+    const bool moved = b->target_x != x || b->target_y != y;
     b->target_x = x;
     b->target_y = y;
-    h->sys[0].targets_dirty = h->sys[1].targets_dirty = true;
+    if (moved) {
+        for (int w = 0; w < 2; ++w) {
+            h->sys[w].targets_dirty = true;
+            h->sys[w].claims_stale = true;  // claims are swept towards the target
+        }
+    }
     return EGG_OK;
 }
 

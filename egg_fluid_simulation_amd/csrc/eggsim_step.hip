@@ -75,7 +75,7 @@ struct Tile {
     uint32_t *own_pack;   // [lcap]        visit lists: other | rank of the pair in other's sequence << 16
                           //               (rank 0 until the rank pass has run)
     uint32_t *inc_tmp;    // [lcap]        scratch: incoming (self | visit-list position << 16)
-    int32_t *aclaim, *aoff, *abatch, *aglob, *aaabb;
+    int32_t *aclaim, *aoff, *abatch, *aglob, *aaabb, *adisp;
     int32_t *sc;  // scalars: 2 particle count; 3 origin x; 4 origin y; 5 misc; 6 gw; 7 gh; 8.. scan carries
     uint16_t *hitems_b;   // [2][nmax]     particles sorted by cell, ascending index inside a cell
     uint16_t *pslot, *aslot, *nlo;
@@ -523,6 +523,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
         t.abatch = (int32_t *)carve(p, a * 4);
         t.aglob = (int32_t *)carve(p, a * 4);
         t.aaabb = (int32_t *)carve(p, a * 4 * 4);
+        t.adisp = (int32_t *)carve(p, a * 4 * 4);
         t.sc = (int32_t *)carve(p, 16 * 4);
         t.hitems_b = (uint16_t *)carve(p, 2 * n * 2);
         t.pslot = (uint16_t *)carve(p, n * 2);
@@ -572,6 +573,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             t.aaabb[4 * k + 1] = 0x7FFFFFFF;
             t.aaabb[4 * k + 2] = -0x7FFFFFFF;
             t.aaabb[4 * k + 3] = -0x7FFFFFFF;
+            for (int q = 0; q < 4; ++q) t.adisp[4 * k + q] = 0;
         }
         t.aoff[na] = off;
         t.sc[2] = off;
@@ -709,6 +711,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 int cy = (fcy >= -2.0e9 && fcy <= 2.0e9) ? (int)fcy : 0x7FFFFFF0;
                 if (cx < cl[0] || cx > cl[2] || cy < cl[1] || cy > cl[3]) {
                     bad = true;
+                    A.atom_fail[A.tile_atoms[a_begin + t.aslot[i]]] = 1;  // tells the host whose claim to widen
                     cx = cl[0];  // keep the data structures in range; the step is discarded anyway
                     cy = cl[1];
                 }
@@ -961,10 +964,22 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
         atomicMin(&t.aaabb[4 * k + 1], cy);
         atomicMax(&t.aaabb[4 * k + 2], cx);
         atomicMax(&t.aaabb[4 * k + 3], cy);
+        // how far the particle moved in the LAST sub-step (= end velocity * sub_delta), per direction,
+        // in 1/16 px: pre-solve continues from exactly that (x += dt * damping * v, L:1411-1418), so the
+        // host can predict the next step's travel and size the claims with it
+        const double2 pvl = regs ? rprev : t.prev[i];
+        const double ddx = ps.x - pvl.x, ddy = ps.y - pvl.y;
+        const int qx = (int)fmin(fmax(ddx * 16.0, -2.0e9), 2.0e9), qy = (int)fmin(fmax(ddy * 16.0, -2.0e9), 2.0e9);
+        atomicMax(&t.adisp[4 * k + (qx >= 0 ? 0 : 1)], abs(qx));
+        atomicMax(&t.adisp[4 * k + (qy >= 0 ? 2 : 3)], abs(qy));
         slack = min(slack, min(min(cx - cl[0], cl[2] - cx), min(cy - cl[1], cl[3] - cy)));
     }
     __syncthreads();
-    for (int q = tid; q < 4 * na; q += nthreads) A.atom_aabb_out[4 * A.tile_atoms[a_begin + (q >> 2)] + (q & 3)] = t.aaabb[q];
+    for (int q = tid; q < 4 * na; q += nthreads) {
+        const int atom = A.tile_atoms[a_begin + (q >> 2)];
+        A.atom_aabb_out[4 * atom + (q & 3)] = t.aaabb[q];
+        A.atom_disp_out[4 * atom + (q & 3)] = t.adisp[q];
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) slack = min(slack, __shfl_xor(slack, d, 64));
     bad = __any(bad);

@@ -171,6 +171,31 @@ def test_batches_that_merge_and_separate(egg, oracle_mod):
     assert tiles[0] == 2 and min(tiles) == 1
 
 
+def test_fast_blobs_keep_their_tiles(egg, oracle_mod):
+    """targets 2.6k px away: the blobs accelerate to ~300 px (38 cells) per step.  Claims are sized per
+    side from the reported last sub-step travel run through the solver's own recurrence, so every
+    step validates at the first attempt; batches whose swept claims reach each other share a tile."""
+    xs, ys = _grid(16, pitch=500.0)
+    h = egg.SimulationHandler()
+    o = oracle_mod.Oracle()
+    ids = h.add_many(xs, ys, 50, 15)
+    for x, y in zip(xs, ys):
+        o.add(float(x), float(y), 50, 15)
+    h.set_target_positions(ids, xs + 2500.0, ys + 900.0)
+    for i, x, y in zip(ids, xs, ys):
+        o.set_target_position(int(i), float(x + 2500.0), float(y + 900.0))
+    tiles = []
+    for _ in range(15):
+        h.update(1 / 60)
+        o.update(1 / 60)
+        tiles.append(h.stats()["n_tiles"][0])
+    _assert_same_state(h, o)
+    moved = h.get_positions(ids)[0] - xs
+    assert moved.min() > 400  # they really did fly
+    assert h.stats()["redo_steps"] <= 2  # predicted, not discovered by failing
+    assert tiles[0] == 16 and min(tiles) >= 4  # at worst the 4 batches of a row (500 px apart) share a tile
+
+
 def test_hand_expanded_division_is_bit_identical_to_operator(egg):
     """the projection's VCC-free division must equal `/` for every operand pair in its window"""
     h = egg.SimulationHandler()

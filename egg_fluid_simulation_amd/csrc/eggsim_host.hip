@@ -73,6 +73,25 @@ struct DevBuf {  // growable device array
     }
 };
 
+template <typename T>
+struct PinnedBuf {  // growable page-locked host array (async copies read/write it without staging)
+    T *p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        size_t ncap = std::max<size_t>(n, cap ? cap * 2 : 1024);
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc((void **)&p, ncap * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = ncap;
+        return e;
+    }
+};
+
 struct Batch {
     int64_t id = 0;
     bool alive = false;
@@ -104,8 +123,7 @@ struct System {  // one particle type
     DevBuf<double> x[2], y[2], vx[2], vy[2], inv_mass, radius, mass_t;
     // atoms (host + device mirrors)
     std::vector<Atom> atoms;
-    DevBuf<int32_t> d_atom_offset, d_atom_count, d_atom_batch, d_atom_claim, d_atom_aabb;
-    DevBuf<double> d_atom_tx, d_atom_ty, d_atom_fd;
+    DevBuf<int32_t> d_atom_offset, d_atom_count, d_atom_batch, d_atom_aabb;
     std::vector<Box> aabb;  // host copy of the atoms' occupied cells
     bool aabb_valid = false;
     bool aabb_on_device = false;  // d_atom_aabb holds the cells of the CURRENT positions (written by the last step)
@@ -119,7 +137,15 @@ struct System {  // one particle type
     DevBuf<int32_t> d_atom_fail;                 // per atom: a particle left the claim in the last launch
     // tiles
     std::vector<int32_t> tile_atom_begin, tile_atoms;
-    DevBuf<int32_t> d_tile_atom_begin, d_tile_atoms;
+    // Per-step metadata (targets, claims, tiles) goes up in ONE async copy from a pinned staging
+    // image; the atoms' end-of-step boxes and travel come back in one async copy behind the kernels.
+    std::vector<double> h_tx, h_ty, h_fd;
+    std::vector<Box> h_claim;
+    bool meta_dirty = true;
+    PinnedBuf<unsigned char> stage_up, stage_down;
+    DevBuf<unsigned char> d_meta;
+    size_t meta_off_ty = 0, meta_off_fd = 0, meta_off_claim = 0, meta_off_tbegin = 0, meta_off_tatoms = 0;
+    bool out_copied = false;  // stage_down holds this launch's boxes / travel
     DevBuf<unsigned char> d_scratch;
     std::vector<LaunchClass> classes;
     int margin = 2;
@@ -315,13 +341,9 @@ int upload_atoms(egg_handle *h, int which) {
         HIP_TRY(h, s.d_atom_offset.reserve(na + 1, false, s.stream));
         HIP_TRY(h, s.d_atom_count.reserve(na + 1, false, s.stream));
         HIP_TRY(h, s.d_atom_batch.reserve(na + 1, false, s.stream));
-        HIP_TRY(h, s.d_atom_claim.reserve(4 * na + 4, false, s.stream));
         HIP_TRY(h, s.d_atom_aabb.reserve(4 * na + 4, false, s.stream));
         HIP_TRY(h, s.d_atom_fail.reserve(na + 1, false, s.stream));
         HIP_TRY(h, s.d_atom_disp.reserve(4 * na + 4, false, s.stream));
-        HIP_TRY(h, s.d_atom_tx.reserve(na + 1, false, s.stream));
-        HIP_TRY(h, s.d_atom_ty.reserve(na + 1, false, s.stream));
-        HIP_TRY(h, s.d_atom_fd.reserve(na + 1, false, s.stream));
         if (na) {
             HIP_TRY(h, hipMemcpy(s.d_atom_offset.p, o.data(), na * 4, hipMemcpyHostToDevice));
             HIP_TRY(h, hipMemcpy(s.d_atom_count.p, c.data(), na * 4, hipMemcpyHostToDevice));
@@ -335,21 +357,18 @@ int upload_atoms(egg_handle *h, int which) {
     }
     if (s.targets_dirty) {
         const size_t na = s.atoms.size();
-        std::vector<double> tx(na), ty(na), fd(na);
+        s.h_tx.resize(na);
+        s.h_ty.resize(na);
+        s.h_fd.resize(na);
         for (size_t k = 0; k < na; ++k) {
             const Batch &B = h->batches[(size_t)s.atoms[k].batch];
-            tx[k] = B.target_x;
-            ty[k] = B.target_y;
+            s.h_tx[k] = B.target_x;
+            s.h_ty[k] = B.target_y;
             // target_distance = 2 * batch_id_to_radius[batch_id], radius = sqrt(batch radius) (L:1454, L:1790)
-            fd[k] = 2 * std::sqrt(which == EGG_WHITE ? B.white_radius : B.yolk_radius);
-        }
-        if (na) {
-            HIP_TRY(h, hipMemcpyAsync(s.d_atom_tx.p, tx.data(), na * 8, hipMemcpyHostToDevice, s.stream));
-            HIP_TRY(h, hipMemcpyAsync(s.d_atom_ty.p, ty.data(), na * 8, hipMemcpyHostToDevice, s.stream));
-            HIP_TRY(h, hipMemcpyAsync(s.d_atom_fd.p, fd.data(), na * 8, hipMemcpyHostToDevice, s.stream));
-            HIP_TRY(h, hipStreamSynchronize(s.stream));  // the staging vectors die here
+            s.h_fd[k] = 2 * std::sqrt(which == EGG_WHITE ? B.white_radius : B.yolk_radius);
         }
         s.targets_dirty = false;
+        s.meta_dirty = true;
     }
     return EGG_OK;
 }
@@ -630,12 +649,8 @@ int retile(egg_handle *h, int which) {
     }
 
     HIP_TRY(h, s.d_scratch.reserve(scratch_bytes + 16, false, s.stream));
-    HIP_TRY(h, s.d_tile_atom_begin.reserve(s.tile_atom_begin.size(), false, s.stream));
-    HIP_TRY(h, s.d_tile_atoms.reserve(s.tile_atoms.size() + 1, false, s.stream));
-    HIP_TRY(h, hipMemcpy(s.d_tile_atom_begin.p, s.tile_atom_begin.data(), s.tile_atom_begin.size() * 4,
-                         hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(s.d_tile_atoms.p, s.tile_atoms.data(), s.tile_atoms.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(s.d_atom_claim.p, claim.data(), na * sizeof(Box), hipMemcpyHostToDevice));
+    s.h_claim = claim;
+    s.meta_dirty = true;
     s.tiling_dirty = false;
     h->stats.retiles++;
     h->stats.n_tiles[which] = (int64_t)tiles.size();
@@ -673,8 +688,33 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     init.min_slack = std::numeric_limits<int32_t>::max();
     *s.h_status = init;
     s.aabb_on_device = false;  // the launch overwrites d_atom_aabb
+    s.out_copied = false;
+    const size_t na = s.atoms.size();
+    if (s.meta_dirty) {
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t nt = s.tile_atom_begin.size();
+        s.meta_off_ty = up16(na * 8);
+        s.meta_off_fd = s.meta_off_ty + up16(na * 8);
+        s.meta_off_claim = s.meta_off_fd + up16(na * 8);
+        s.meta_off_tbegin = s.meta_off_claim + up16(na * sizeof(Box));
+        s.meta_off_tatoms = s.meta_off_tbegin + up16(nt * 4);
+        const size_t bytes = s.meta_off_tatoms + up16(s.tile_atoms.size() * 4 + 4);
+        HIP_TRY(h, s.stage_up.reserve(bytes));
+        HIP_TRY(h, s.d_meta.reserve(bytes, false, s.stream));
+        unsigned char *b = s.stage_up.p;
+        memcpy(b, s.h_tx.data(), na * 8);
+        memcpy(b + s.meta_off_ty, s.h_ty.data(), na * 8);
+        memcpy(b + s.meta_off_fd, s.h_fd.data(), na * 8);
+        memcpy(b + s.meta_off_claim, s.h_claim.data(), na * sizeof(Box));
+        memcpy(b + s.meta_off_tbegin, s.tile_atom_begin.data(), nt * 4);
+        memcpy(b + s.meta_off_tatoms, s.tile_atoms.data(), s.tile_atoms.size() * 4);
+        // safe to reuse the staging image: every earlier copy out of it has completed (each step ends
+        // with a stream synchronise)
+        HIP_TRY(h, hipMemcpyAsync(s.d_meta.p, b, bytes, hipMemcpyHostToDevice, s.stream));
+        s.meta_dirty = false;
+    }
     HIP_TRY(h, hipMemcpyAsync(s.d_status, s.h_status, sizeof(EggStatus), hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(h, hipMemsetAsync(s.d_atom_fail.p, 0, (s.atoms.size() + 1) * sizeof(int32_t), s.stream));
+    HIP_TRY(h, hipMemsetAsync(s.d_atom_fail.p, 0, (na + 1) * sizeof(int32_t), s.stream));
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev0, s.stream));
     for (const LaunchClass &lc : s.classes) {
         EggStepArgs A;
@@ -693,15 +733,15 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.atom_offset = s.d_atom_offset.p;
         A.atom_count = s.d_atom_count.p;
         A.atom_batch = s.d_atom_batch.p;
-        A.atom_tx = s.d_atom_tx.p;
-        A.atom_ty = s.d_atom_ty.p;
-        A.atom_fd = s.d_atom_fd.p;
-        A.atom_claim = s.d_atom_claim.p;
+        A.atom_tx = (const double *)s.d_meta.p;
+        A.atom_ty = (const double *)(s.d_meta.p + s.meta_off_ty);
+        A.atom_fd = (const double *)(s.d_meta.p + s.meta_off_fd);
+        A.atom_claim = (const int32_t *)(s.d_meta.p + s.meta_off_claim);
         A.atom_aabb_out = s.d_atom_aabb.p;
         A.atom_fail = s.d_atom_fail.p;
         A.atom_disp_out = s.d_atom_disp.p;
-        A.tile_atom_begin = s.d_tile_atom_begin.p + lc.first_tile;
-        A.tile_atoms = s.d_tile_atoms.p;
+        A.tile_atom_begin = (const int32_t *)(s.d_meta.p + s.meta_off_tbegin) + lc.first_tile;
+        A.tile_atoms = (const int32_t *)(s.d_meta.p + s.meta_off_tatoms);
         A.n_tiles = lc.n_tiles;
         A.sub_delta = env.sub_delta;
         A.damping = env.damping;
@@ -737,6 +777,14 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     }
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev1, s.stream));
     HIP_TRY(h, hipMemcpyAsync(s.h_status, s.d_status, sizeof(EggStatus), hipMemcpyDeviceToHost, s.stream));
+    if (na && na <= 65536) {
+        // the atoms' end-of-step cell boxes and last-sub-step travel ride back behind the status: the
+        // next tiling (every step while targets move) then needs no further round trip
+        HIP_TRY(h, s.stage_down.reserve(na * 32));
+        HIP_TRY(h, hipMemcpyAsync(s.stage_down.p, s.d_atom_aabb.p, na * 16, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipMemcpyAsync(s.stage_down.p + na * 16, s.d_atom_disp.p, na * 16, hipMemcpyDeviceToHost, s.stream));
+        s.out_copied = true;
+    }
     return EGG_OK;
 }
 
@@ -887,9 +935,18 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
             const int np = std::min(S * C, EGG_MAX_PASSES);
             for (int p = 0; p < np; ++p) h->stats.pair_solves += (int64_t)st.visits[p];
             h->stats.follow_solves += s.n * S;
-            s.aabb_valid = false;  // d_atom_aabb now holds end-of-step cells; fetched on demand
-            s.disp_valid = false;
-            s.aabb_on_device = true;
+            s.aabb_on_device = true;  // d_atom_aabb now holds end-of-step cells
+            if (s.out_copied) {
+                const size_t na = s.atoms.size();
+                s.aabb.resize(na);
+                s.disp.resize(4 * na);
+                memcpy(s.aabb.data(), s.stage_down.p, na * 16);
+                memcpy(s.disp.data(), s.stage_down.p + na * 16, na * 16);
+                s.aabb_valid = s.disp_valid = true;
+            } else {
+                s.aabb_valid = false;  // fetched on demand
+                s.disp_valid = false;
+            }
             if (st.min_slack < s.margin || s.swept) {
                 // some particle has used part of its margin, or blobs are flying: re-tile around the
                 // new positions

@@ -33,6 +33,8 @@ OPT_TIMING = 2
 OPT_FORCE_SINGLE_TILE = 3
 OPT_THREADS_PER_PARTICLE = 4
 OPT_SPIN_SLEEP = 5
+OPT_BUDGET_PARTICLES_WHITE = 6
+OPT_BUDGET_PARTICLES_YOLK = 7
 
 CONFIG_FIELDS = ["damping", "follow_strength", "cohesion_strength",
                  "cohesion_interaction_distance_factor", "collision_strength",
@@ -42,6 +44,11 @@ CONFIG_FIELDS = ["damping", "follow_strength", "cohesion_strength",
 
 class EggConfig(C.Structure):
     _fields_ = [(k, C.c_double) for k in CONFIG_FIELDS]
+
+
+class EggBatchInfo(C.Structure):
+    _fields_ = [("key", C.c_int64), ("target_x", C.c_double), ("target_y", C.c_double), ("white_radius", C.c_double),
+                ("yolk_radius", C.c_double), ("n_white", C.c_int64), ("n_yolk", C.c_int64)]
 
 
 class EggStats(C.Structure):
@@ -64,6 +71,10 @@ _SIGNATURES = {
                           C.POINTER(C.c_int64)]),
     "egg_add_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                C.c_int64, C.c_int64, C.c_void_p]),
+    "egg_add_many_keyed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                     C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "egg_export_batch": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(EggBatchInfo), C.c_void_p, C.c_void_p]),
+    "egg_import_batch": (C.c_int, [C.c_void_p, C.POINTER(EggBatchInfo), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "egg_remove": (C.c_int, [C.c_void_p, C.c_int64]),
     "egg_set_target": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double]),
     "egg_set_targets_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -98,6 +98,7 @@ struct Batch {
     double target_x = 0, target_y = 0;
     double white_radius = 0, yolk_radius = 0;
     int64_t n[2] = {0, 0};
+    int64_t key = 0;  // position in the global creation order; particles are laid out in ascending key
 };
 
 struct Atom {
@@ -172,6 +173,9 @@ struct egg_handle {
     int device = 0;
     System sys[2];
     std::vector<Batch> batches;  // index = id - 1 (ids are never reused, L:999-1000)
+    std::vector<int32_t> order;  // indices of the live batches in ascending key = particle layout order
+    int64_t next_key = 1;
+    int64_t budget_particles[2] = {-1, -1};  // >= 0: particle count of the budget 0.05 N^2 (multi-GPU: global N)
     int64_t n_alive = 0;
     double elapsed = 0, interpolation_alpha = 0;
     egg_stats stats{};
@@ -321,8 +325,8 @@ int upload_atoms(egg_handle *h, int which) {
     if (s.atoms_dirty) {
         s.atoms.clear();
         int64_t off = 0;
-        for (size_t b = 0; b < h->batches.size(); ++b) {
-            const Batch &B = h->batches[b];
+        for (int32_t b : h->order) {
+            const Batch &B = h->batches[(size_t)b];
             if (!B.alive) continue;
             Atom a;
             a.batch = (int32_t)b;
@@ -797,7 +801,7 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
     Env env[2];
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];
-        env[w] = make_env(s.cfg, sub_delta, s.n);
+        env[w] = make_env(s.cfg, sub_delta, h->budget_particles[w] >= 0 ? h->budget_particles[w] : s.n);
         // mass / radius follow a config change at the next step (L:1731-1744, L:1420-1430)
         bool upd_mass = !s.has_env || s.cfg.min_mass != s.env_min_mass || s.cfg.max_mass != s.env_max_mass;
         bool upd_radius = !s.has_env || s.cfg.min_radius != s.env_min_radius || s.cfg.max_radius != s.env_max_radius;
@@ -1121,8 +1125,30 @@ int egg_get_config(const egg_handle *h, int which, egg_config *cfg) {
     return EGG_OK;
 }
 
+static int add_many_impl(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
+                         double yolk_radius, int64_t white_n, int64_t yolk_n, const int64_t *keys, int64_t *out_ids);
+
 int egg_add_many(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
                  double yolk_radius, int64_t white_n, int64_t yolk_n, int64_t *out_ids) {
+    return add_many_impl(h, n, xs, ys, white_radius, yolk_radius, white_n, yolk_n, nullptr, out_ids);
+}
+
+int egg_add_many_keyed(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
+                       double yolk_radius, int64_t white_n, int64_t yolk_n, const int64_t *keys, int64_t *out_ids) {
+    if (!h || !keys) return EGG_ERR_INVALID_ARGUMENT;
+    int64_t last = h->next_key - 1;
+    for (int64_t k = 0; k < n; ++k) {
+        if (keys[k] <= last)
+            return fail(h, EGG_ERR_INVALID_ARGUMENT,
+                        "egg_add_many_keyed: keys must ascend and exceed every key in the handler (use egg_import_batch "
+                        "to insert in the middle)");
+        last = keys[k];
+    }
+    return add_many_impl(h, n, xs, ys, white_radius, yolk_radius, white_n, yolk_n, keys, out_ids);
+}
+
+static int add_many_impl(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
+                         double yolk_radius, int64_t white_n, int64_t yolk_n, const int64_t *keys, int64_t *out_ids) {
     if (!h || n < 0 || (n > 0 && (!xs || !ys))) return EGG_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(h->device);
     const egg_config &wc = h->sys[0].cfg, &yc = h->sys[1].cfg;
@@ -1166,6 +1192,9 @@ int egg_add_many(egg_handle *h, int64_t n, const double *xs, const double *ys, d
         b.yolk_radius = yolk_radius;
         b.n[0] = white_n;
         b.n[1] = yolk_n;
+        b.key = keys ? keys[k] : h->next_key;
+        h->next_key = b.key + 1;
+        h->order.push_back((int32_t)h->batches.size());
         h->batches.push_back(b);
         h->n_alive++;
         if (out_ids) out_ids[k] = b.id;
@@ -1218,6 +1247,7 @@ int egg_remove(egg_handle *h, int64_t id) {  // L:140-155, L:1037-1106
     }
     b->alive = false;
     h->n_alive--;
+    h->order.erase(std::remove(h->order.begin(), h->order.end(), (int32_t)(id - 1)), h->order.end());
     return EGG_OK;
 }
 
@@ -1421,11 +1451,11 @@ int egg_get_n_particles(const egg_handle *h, int64_t id, int64_t *n_white, int64
 int egg_list_ids(const egg_handle *h, int64_t cap, int64_t *ids, int64_t *n) {  // L:399-405
     if (!h || !n) return EGG_ERR_INVALID_ARGUMENT;
     int64_t k = 0;
-    for (const Batch &b : h->batches)
-        if (b.alive) {
-            if (ids && k < cap) ids[k] = b.id;
-            ++k;
-        }
+    for (int32_t bi : h->order) {
+        const Batch &b = h->batches[(size_t)bi];
+        if (ids && k < cap) ids[k] = b.id;
+        ++k;
+    }
     *n = k;
     return EGG_OK;
 }
@@ -1467,6 +1497,98 @@ int egg_download_particles(egg_handle *h, int which, int field, double *dst, int
     }
     HIP_TRY(h, hipMemcpyAsync(dst, src, (size_t)s.n * 8, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(h, hipStreamSynchronize(s.stream));
+    return EGG_OK;
+}
+
+// ---- multi-GPU hand-over: a batch leaves one handler and enters another with its full state ----
+
+static const int kExportFields = 9;  // x y vx vy last_x last_y inv_mass radius mass_t
+
+int egg_export_batch(egg_handle *h, int64_t id, egg_batch_info *info, double *white_state, double *yolk_state) {
+    if (!h || !info) return EGG_ERR_INVALID_ARGUMENT;
+    const Batch *b = find_batch(h, id);
+    if (!b) return fail(h, EGG_ERR_UNKNOWN_ID, "egg_export_batch: no batch with id `%lld`", (long long)id);
+    (void)hipSetDevice(h->device);
+    info->key = b->key;
+    info->target_x = b->target_x;
+    info->target_y = b->target_y;
+    info->white_radius = b->white_radius;
+    info->yolk_radius = b->yolk_radius;
+    info->n_white = b->n[0];
+    info->n_yolk = b->n[1];
+    for (int w = 0; w < 2; ++w) {
+        double *dst = w == 0 ? white_state : yolk_state;
+        if (!dst) continue;
+        System &s = h->sys[w];
+        int rc = upload_atoms(h, w);
+        if (rc != EGG_OK) return rc;
+        const Atom *at = nullptr;
+        for (const Atom &a : s.atoms)
+            if (a.batch == (int32_t)(id - 1)) at = &a;
+        if (!at) return fail(h, EGG_ERR_INTERNAL, "egg_export_batch: atom not found");
+        const double *src[kExportFields] = {s.x[s.cur].p,     s.y[s.cur].p,     s.vx[s.cur].p, s.vy[s.cur].p, s.x[s.cur ^ 1].p,
+                                            s.y[s.cur ^ 1].p, s.inv_mass.p, s.radius.p,    s.mass_t.p};
+        for (int f = 0; f < kExportFields; ++f)
+            HIP_TRY(h, hipMemcpyAsync(dst + (size_t)f * at->count, src[f] + at->offset, (size_t)at->count * 8,
+                                      hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipStreamSynchronize(s.stream));
+    }
+    return EGG_OK;
+}
+
+int egg_import_batch(egg_handle *h, const egg_batch_info *info, const double *white_state, const double *yolk_state,
+                     int64_t *out_id) {
+    if (!h || !info || !white_state || !yolk_state || info->n_white < 1 || info->n_yolk < 1)
+        return EGG_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(h->device);
+    // position in the layout order
+    size_t pos = 0;
+    while (pos < h->order.size() && h->batches[(size_t)h->order[pos]].key < info->key) ++pos;
+    if (pos < h->order.size() && h->batches[(size_t)h->order[pos]].key == info->key)
+        return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_import_batch: key %lld is already present", (long long)info->key);
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        const int64_t cnt = w == 0 ? info->n_white : info->n_yolk;
+        const double *src = w == 0 ? white_state : yolk_state;
+        int64_t at = 0;
+        for (size_t k = 0; k < pos; ++k) at += h->batches[(size_t)h->order[k]].n[w];
+        int rc = reserve_particles(h, s, s.n + cnt);
+        if (rc != EGG_OK) return rc;
+        const size_t tail = (size_t)(s.n - at);
+        double *arrays[11] = {s.x[s.cur].p, s.y[s.cur].p, s.vx[s.cur].p, s.vy[s.cur].p, s.x[s.cur ^ 1].p, s.y[s.cur ^ 1].p,
+                              s.inv_mass.p, s.radius.p,   s.mass_t.p,    s.vx[s.cur ^ 1].p, s.vy[s.cur ^ 1].p};
+        const int field_of[11] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 2, 3};
+        DevBuf<double> tmp;
+        if (tail) HIP_TRY(h, tmp.reserve(tail, false, s.stream));
+        for (int a = 0; a < 11; ++a) {
+            if (tail) {  // open a gap: order-preserving shift of the tail
+                HIP_TRY(h, hipMemcpyAsync(tmp.p, arrays[a] + at, tail * 8, hipMemcpyDeviceToDevice, s.stream));
+                HIP_TRY(h, hipMemcpyAsync(arrays[a] + at + cnt, tmp.p, tail * 8, hipMemcpyDeviceToDevice, s.stream));
+            }
+            HIP_TRY(h, hipMemcpyAsync(arrays[a] + at, src + (size_t)field_of[a] * cnt, (size_t)cnt * 8,
+                                      hipMemcpyHostToDevice, s.stream));
+        }
+        HIP_TRY(h, hipStreamSynchronize(s.stream));
+        s.n += cnt;
+        s.atoms_dirty = s.targets_dirty = s.tiling_dirty = true;
+        s.aabb_valid = s.aabb_on_device = false;
+        s.disp_valid = false;
+    }
+    Batch b;
+    b.id = (int64_t)h->batches.size() + 1;
+    b.alive = true;
+    b.key = info->key;
+    b.target_x = info->target_x;
+    b.target_y = info->target_y;
+    b.white_radius = info->white_radius;
+    b.yolk_radius = info->yolk_radius;
+    b.n[0] = info->n_white;
+    b.n[1] = info->n_yolk;
+    h->order.insert(h->order.begin() + (long)pos, (int32_t)h->batches.size());
+    h->batches.push_back(b);
+    h->n_alive++;
+    if (info->key >= h->next_key) h->next_key = info->key + 1;
+    if (out_id) *out_id = b.id;
     return EGG_OK;
 }
 
@@ -1518,6 +1640,10 @@ int egg_set_option(egg_handle *h, int option, double value) {
         case EGG_OPT_THREADS_PER_PARTICLE:
             if (value != 1 && value != 2 && value != 4) return fail(h, EGG_ERR_INVALID_ARGUMENT, "threads per particle must be 1, 2 or 4");
             h->opt_spread = (int)value;
+            return EGG_OK;
+        case EGG_OPT_BUDGET_PARTICLES_WHITE:
+        case EGG_OPT_BUDGET_PARTICLES_YOLK:
+            h->budget_particles[option == EGG_OPT_BUDGET_PARTICLES_WHITE ? 0 : 1] = value < 0 ? -1 : (int64_t)value;
             return EGG_OK;
         case EGG_OPT_SPIN_SLEEP:
             h->opt_spin_sleep = value < 0 ? -1 : (value != 0);

@@ -14,9 +14,18 @@ batches that provably cannot interact.  Sharding therefore works on whole batche
     per boundary batch instead of per-particle records;
   * a ghost box within interaction range of a local batch means the two batches could meet in
     this step.  Exact Gauss-Seidel order across a cut cannot be kept in parallel (8e, exactness
-    caveat), so that pair must be stepped by ONE rank; handing the batch over is not implemented
-    in this round and SlabConflict is raised instead (tiled benchmarks never trigger it).
+    caveat), so that pair must be stepped by ONE rank: ShardedSimulationHandler hands the batch of
+    the higher rank over to the lower rank (complete particle state, egg_export_batch /
+    egg_import_batch) before the step, and hands batches that have strayed deep into another slab
+    to that slab's rank.  Every handler lays its particles out in ascending global batch id, so the
+    result is bit-identical to one handler holding everything.  BoundaryExchange alone (bench.py)
+    raises SlabConflict instead of migrating.
+
+Not covered: the collision budget's exact-mode (a type with so few particles that 0.05 N^2 visits
+can bind) needs all particles in one tile and therefore on one rank.
 """
+import math
+
 import numpy as np
 
 
@@ -103,9 +112,9 @@ class BoundaryExchange:
             out += [(int(i), int(gid)) for i in ids[near]]
         return out
 
-    def exchange(self):
-        """Swap boundary boxes with both neighbours.  Returns the conflicts found (and raises
-        SlabConflict if there are any)."""
+    def exchange(self, raise_on_conflict=True):
+        """Swap boundary boxes with both neighbours.  Returns the conflicts found as
+        (local id, ghost id, ghost rank); raises SlabConflict for them unless told otherwise."""
         if self.world == 1:
             return []
         torch, dist = self.torch, self.dist
@@ -136,9 +145,187 @@ class BoundaryExchange:
             self.ghosts[r] = (gids, gboxes)
             self.bytes_exchanged += 8 * (2 + self.RECORD * (n + self.sent[r]))
             found += [(i, g, r) for i, g in self.conflicts(ids, boxes, gids, gboxes, self.interact_px)]
-        if found or outside.any():
+        self.last_ids, self.last_boxes = ids, boxes
+        if raise_on_conflict and (found or outside.any()):
             raise SlabConflict(
                 "rank %d: %d local/ghost batch pairs within %.0f px across a slab cut (first: %s), %d local batches "
                 "outside their slab; handing batches over between ranks is not implemented"
                 % (self.rank, len(found), self.interact_px, found[:1], int(outside.sum())))
         return found
+
+
+class ShardedSimulationHandler:
+    """SimulationHandler spread over the ranks of a process group, one x-slab per rank.
+
+    SPMD: every rank makes the same add / set_target_position / update calls with the same
+    arguments; batch ids are global.  `make_handler` builds the local device handler (tests inject
+    their own).  Results equal a single handler's bit for bit (tests/test_gpu_sharded.py).
+    """
+
+    STATE_FIELDS = 9
+
+    def __init__(self, layout, rank, group, make_handler, halo_px=64.0, interact_px=48.0, device=None):
+        import torch
+        self.torch, self.dist = torch, group
+        self.layout, self.rank, self.world = layout, int(rank), layout.world
+        self.local = make_handler()
+        self.owner = {}       # global id -> rank
+        self.local_id = {}    # global id -> id in self.local (batches this rank owns)
+        self.global_id = {}   # local id -> global id
+        self.radii = {}       # global id -> (white_radius, yolk_radius)
+        self.next_gid = 1
+        self.migrations = 0
+        lo, hi = layout.bounds(rank)
+        self.exchange = BoundaryExchange(None, rank, self.world, lo, hi, group=group, halo_px=halo_px,
+                                         interact_px=interact_px, bounds_fn=self._bounds, device=device)
+        self.device = self.exchange.device if self.world > 1 else "cpu"
+
+    # ------------------------------------------------------------------ API
+    def add(self, x, y, white_radius=50.0, yolk_radius=15.0):
+        gid = self.next_gid
+        self.next_gid += 1
+        r = int(self.layout.owner_of([x])[0])
+        self.owner[gid] = r
+        self.radii[gid] = (white_radius, yolk_radius)
+        if r == self.rank:
+            lid = int(self.local.add_many_keyed([x], [y], [gid], white_radius, yolk_radius)[0])
+            self.local_id[gid] = lid
+            self.global_id[lid] = gid
+        self._sync_budget()
+        return gid
+
+    def set_target_position(self, gid, x, y):
+        if self.owner[gid] == self.rank:
+            self.local.set_target_position(self.local_id[gid], x, y)
+
+    def update(self, delta, step_delta=None, n_substeps=None, n_collision_steps=None):
+        self.rebalance()
+        return self.local.update(delta, step_delta, n_substeps, n_collision_steps)
+
+    def positions(self):
+        """{global id: (x, y)} of every batch, gathered on all ranks"""
+        mine = {g: self.local.get_position(l) for g, l in self.local_id.items()}
+        if self.world == 1:
+            return mine
+        out = [None] * self.world
+        self.dist.all_gather_object(out, mine)
+        merged = {}
+        for d in out:
+            merged.update(d)
+        return merged
+
+    def particles(self, which):
+        """{global id: (x[n], y[n])} of this rank's batches"""
+        x, y, b = self.local.download(which, "x"), self.local.download(which, "y"), self.local.download(which, "batch_id")
+        return {self.global_id[int(l)]: (x[b == l], y[b == l]) for l in np.unique(b)}
+
+    # ------------------------------------------------------------ internals
+    def _bounds(self):
+        gids = np.array(sorted(self.local_id), dtype=np.int64)
+        if len(gids) == 0:
+            return gids, np.zeros((0, 4))
+        return gids, self.local.get_bounds([self.local_id[int(g)] for g in gids])
+
+    def _sync_budget(self):
+        # the budget 0.05 N^2 counts the particles of ALL ranks (simulation_handler.lua:1752-1753)
+        from . import _ffi
+        nw = ny = 0
+        for g, (wr, yr) in self.radii.items():
+            nw += int(math.ceil((wr * wr) / 16.0))
+            ny += int(math.ceil((yr * yr) / 16.0))
+        if self.world > 1:
+            self.local.set_option(_ffi.OPT_BUDGET_PARTICLES_WHITE, nw)
+            self.local.set_option(_ffi.OPT_BUDGET_PARTICLES_YOLK, ny)
+
+    def _send_batch(self, gid, to):
+        torch, dist = self.torch, self.dist
+        info, ws, ys = self.local.export_batch(self.local_id[gid])
+        head = torch.tensor([gid, info["target_x"], info["target_y"], info["white_radius"], info["yolk_radius"],
+                             info["n_white"], info["n_yolk"]], dtype=torch.float64, device=self.device)
+        dist.send(head, to)
+        dist.send(torch.from_numpy(ws).reshape(-1).to(self.device), to)
+        dist.send(torch.from_numpy(ys).reshape(-1).to(self.device), to)
+        lid = self.local_id.pop(gid)
+        del self.global_id[lid]
+        self.local.remove(lid)
+
+    def _recv_batch(self, frm):
+        torch, dist = self.torch, self.dist
+        head = torch.zeros(7, dtype=torch.float64, device=self.device)
+        dist.recv(head, frm)
+        hgid, tx, ty, wr, yr, nw, ny = head.cpu().tolist()
+        gid, nw, ny = int(hgid), int(nw), int(ny)
+        ws = torch.zeros(self.STATE_FIELDS * nw, dtype=torch.float64, device=self.device)
+        ys = torch.zeros(self.STATE_FIELDS * ny, dtype=torch.float64, device=self.device)
+        dist.recv(ws, frm)
+        dist.recv(ys, frm)
+        info = dict(key=gid, target_x=tx, target_y=ty, white_radius=wr, yolk_radius=yr, n_white=nw, n_yolk=ny)
+        lid = self.local.import_batch(info, ws.cpu().numpy().reshape(self.STATE_FIELDS, nw),
+                                      ys.cpu().numpy().reshape(self.STATE_FIELDS, ny))
+        self.local_id[gid] = lid
+        self.global_id[lid] = gid
+        return gid
+
+    def rebalance(self, max_rounds=None):
+        """Before a step: exchange boundary boxes and hand batches over until no local batch is within
+        interaction range of another rank's batch.  Conflicts move the higher rank's batch down;
+        batches that strayed past the halo of their slab move to the slab they are in."""
+        if self.world == 1:
+            return 0
+        torch, dist = self.torch, self.dist
+        moved_total = 0
+        for _ in range(max_rounds or 2 * self.world + 2):
+            conflicts = self.exchange.exchange(raise_on_conflict=False)
+            ids, boxes = self.exchange.last_ids, self.exchange.last_boxes
+            lo, hi = self.exchange.slab_lo, self.exchange.slab_hi
+            to_left, to_right, want_right = set(), set(), set()
+            for lid_g, ghost, ghost_rank in conflicts:
+                if ghost_rank < self.rank:
+                    to_left.add(int(lid_g))   # the lower rank steps the pair
+                else:
+                    want_right.add(int(ghost))  # its owner may not see my batch: ask for it
+            in_conflict = {int(c[0]) for c in conflicts}
+            for g, b in zip(ids, boxes):
+                g = int(g)
+                if g in in_conflict:
+                    continue
+                if self.rank > 0 and b[2] < lo - self.exchange.halo_px:
+                    to_left.add(g)
+                elif self.rank + 1 < self.world and b[0] > hi + self.exchange.halo_px:
+                    to_right.add(g)
+            # everyone learns every plan: how many batches arrive from whom, and the new owner table
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, (sorted(to_left), sorted(to_right), sorted(want_right)))
+            plan = []
+            for r, (l, rr, _w) in enumerate(gathered):
+                wanted = set(gathered[r - 1][2]) if r > 0 else set()
+                l = sorted(set(l) | {g for g in wanted if self.owner.get(g) == r})
+                plan.append((l, [g for g in rr if g not in l]))
+            to_left, to_right = set(plan[self.rank][0]), set(plan[self.rank][1])
+            n_moves = sum(len(l) + len(r) for l, r in plan)
+            if n_moves == 0:
+                if conflicts:
+                    raise SlabConflict("rank %d: unresolved cross-slab pairs %s" % (self.rank, conflicts[:3]))
+                return moved_total
+            # even ranks send first, odd ranks receive first: neighbour pairs never both block in send
+            for phase in (0, 1):
+                if self.rank % 2 == phase:
+                    for g in sorted(to_left):
+                        self._send_batch(g, self.rank - 1)
+                    for g in sorted(to_right):
+                        self._send_batch(g, self.rank + 1)
+                else:
+                    if self.rank + 1 < self.world:
+                        for _g in plan[self.rank + 1][0]:
+                            self._recv_batch(self.rank + 1)
+                    if self.rank > 0:
+                        for _g in plan[self.rank - 1][1]:
+                            self._recv_batch(self.rank - 1)
+            for r, (l, rr) in enumerate(plan):
+                for g in l:
+                    self.owner[g] = r - 1
+                for g in rr:
+                    self.owner[g] = r + 1
+            moved_total += n_moves
+            self.migrations += n_moves
+        raise SlabConflict("rank %d: batch hand-over did not settle" % self.rank)

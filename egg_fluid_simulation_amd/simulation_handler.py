@@ -242,6 +242,35 @@ class SimulationHandler:
             0 if yolk_n_particles is None else int(yolk_n_particles), ids.ctypes.data))
         return ids
 
+    def add_many_keyed(self, xs, ys, keys, white_radius=None, yolk_radius=None):
+        """`add_many` with explicit global-order keys (multi-GPU sharding, see include/eggsim.h)"""
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        ids = np.empty(xs.shape[0], dtype=np.int64)
+        self._check(self._lib.egg_add_many_keyed(
+            self._h, xs.shape[0], xs.ctypes.data, ys.ctypes.data,
+            float("nan") if white_radius is None else float(white_radius),
+            float("nan") if yolk_radius is None else float(yolk_radius), 0, 0, keys.ctypes.data, ids.ctypes.data))
+        return ids
+
+    def export_batch(self, batch_id):
+        """(info dict, white_state[9, n_w], yolk_state[9, n_y]) of a batch: everything another handler
+        needs to continue it bit for bit"""
+        nw, ny = self.get_n_particles(batch_id)
+        info = _ffi.EggBatchInfo()
+        ws, ys = np.empty((9, nw)), np.empty((9, ny))
+        self._check(self._lib.egg_export_batch(self._h, int(batch_id), C.byref(info), ws.ctypes.data, ys.ctypes.data))
+        return {k: getattr(info, k) for k, _ in _ffi.EggBatchInfo._fields_}, ws, ys
+
+    def import_batch(self, info, white_state, yolk_state):
+        c = _ffi.EggBatchInfo(**{k: info[k] for k, _ in _ffi.EggBatchInfo._fields_})
+        ws = np.ascontiguousarray(white_state, dtype=np.float64)
+        ys = np.ascontiguousarray(yolk_state, dtype=np.float64)
+        out = C.c_int64()
+        self._check(self._lib.egg_import_batch(self._h, C.byref(c), ws.ctypes.data, ys.ctypes.data, C.byref(out)))
+        return out.value
+
     def remove(self, batch_id):  # L:140-155
         _assert_types(batch_id, "number")
         rc = self._check(self._lib.egg_remove(self._h, int(batch_id)))

@@ -88,6 +88,26 @@ int egg_add(egg_handle *h, double x, double y, double white_radius, double yolk_
 /* n batches with identical radii in one call (bulk form for 10^4..10^5 batches) */
 int egg_add_many(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
                  double yolk_radius, int64_t white_n, int64_t yolk_n, int64_t *out_ids);
+/* Multi-GPU sharding.  The reference keeps every batch of a handler in ONE array in creation order
+ * (L:964-993), and the pair solver's results depend on that order.  When the batches are spread over
+ * several handlers (one per GPU), each handler must lay its particles out in the global creation
+ * order restricted to its batches: `key` is a batch's position in that global order.
+ * egg_add_many_keyed appends (keys ascending and larger than every key present); egg_export_batch /
+ * egg_import_batch move a batch with its complete particle state between handlers, the import
+ * inserting it at its key's place.  State layout: 9 fields x n particles, field-major:
+ * x, y, vx, vy, last_x, last_y, inv_mass, radius, mass_t. */
+typedef struct {
+    int64_t key;
+    double target_x, target_y;
+    double white_radius, yolk_radius;
+    int64_t n_white, n_yolk;
+} egg_batch_info;
+int egg_add_many_keyed(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
+                       double yolk_radius, int64_t white_n, int64_t yolk_n, const int64_t *keys, int64_t *out_ids);
+int egg_export_batch(egg_handle *h, int64_t id, egg_batch_info *info, double *white_state, double *yolk_state);
+int egg_import_batch(egg_handle *h, const egg_batch_info *info, const double *white_state, const double *yolk_state,
+                     int64_t *out_id);
+
 /* remove(id) (L:140-155, L:1037-1106) */
 int egg_remove(egg_handle *h, int64_t id);
 
@@ -161,7 +181,9 @@ enum {
     EGG_OPT_TIMING,                 /* 1: record HIP events around the step kernels */
     EGG_OPT_FORCE_SINGLE_TILE,      /* 1: always run each type as one tile (exact budget path) */
     EGG_OPT_THREADS_PER_PARTICLE,   /* 1, 2 or 4: spread a tile's particles over more waves (latency vs occupancy) */
-    EGG_OPT_SPIN_SLEEP              /* -1 auto, 0 never, 1 always: idle dataflow waves sleep between polls */
+    EGG_OPT_SPIN_SLEEP,             /* -1 auto, 0 never, 1 always: idle dataflow waves sleep between polls */
+    EGG_OPT_BUDGET_PARTICLES_WHITE, /* multi-GPU: N of the collision budget 0.05 N^2 (L:1752-1753) = particles of ALL ranks; -1 = local */
+    EGG_OPT_BUDGET_PARTICLES_YOLK
 };
 int egg_set_option(egg_handle *h, int option, double value);
 

@@ -1,0 +1,111 @@
+"""Two ranks (two processes, one handler each on the same GPU, gloo for the exchange -- the GPU box
+has one card; the code path is the one nccl/RCCL runs over xGMI) against ONE CPU oracle holding all
+batches: columns of batches are driven across the slab cut into each other, so batches are handed
+over between ranks mid-run.  Positions must match the single-handler result bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+N_STEPS = 70
+
+
+def _scenario():
+    """10 batches in two columns either side of the cut at x = 1000, 300 px apart inside a column (so
+    only opposite batches meet, as pairs); targets make the columns swap sides.  10 batches keep the
+    yolk collision budget from binding (it binds for <= 9 batches)."""
+    centers = [(760.0, 150.0 + 300.0 * k) for k in range(5)] + [(1240.0, 150.0 + 300.0 * k) for k in range(5)]
+
+    def target(gid, step):
+        cx, cy = centers[gid - 1]
+        t = min(1.0, step / 40.0)
+        return (cx + (480.0 if cx < 1000 else -480.0) * t, cy + 10.0 * t)
+
+    return centers, target
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from egg_fluid_simulation_amd import SimulationHandler
+    from egg_fluid_simulation_amd.sharding import ShardedSimulationHandler, SlabLayout
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        centers, target = _scenario()
+        layout = SlabLayout([0.0, 1000.0, 2000.0])
+        sh = ShardedSimulationHandler(layout, rank, dist, lambda: SimulationHandler(device=0), device="cpu")
+        gids = [sh.add(x, y, 50, 15) for x, y in centers]
+        owners0 = dict(sh.owner)
+        for k in range(N_STEPS):
+            for g in gids:
+                sh.set_target_position(g, *target(g, k))
+            assert sh.update(1 / 60) == 1
+        white = {g: (x.tolist(), y.tolist()) for g, (x, y) in sh.particles(0).items()}
+        yolk = {g: (x.tolist(), y.tolist()) for g, (x, y) in sh.particles(1).items()}
+        pos = sh.positions()
+        q.put((rank, white, yolk, pos, sh.migrations, owners0, dict(sh.owner)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_hand_over_match_single_handler(oracle_mod):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    import queue
+    import time
+    deadline = time.time() + 240
+    while len(res) < 2 and time.time() < deadline:
+        try:
+            out = q.get(timeout=2)
+            res[out[0]] = out
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    for p in procs:
+        p.join(20)
+        if p.is_alive():
+            p.kill()  # the exact child started above
+    assert len(res) == 2 and all(p.exitcode == 0 for p in procs), "a rank failed: see its traceback above"
+
+    centers, target = _scenario()
+    o = oracle_mod.Oracle()
+    gids = [o.add(x, y, 50, 15) for x, y in centers]
+    for k in range(N_STEPS):
+        for g in gids:
+            o.set_target_position(g, *target(g, k))
+        o.update(1 / 60)
+    for which in (0, 1):
+        x, y, b = o.field(which, "x"), o.field(which, "y"), o.field(which, "batch_id")
+        seen = set()
+        for r in (0, 1):
+            for g, (gx, gy) in res[r][1 + which].items():
+                assert g not in seen
+                seen.add(g)
+                assert np.array_equal(np.array(gx), x[b == g]) and np.array_equal(np.array(gy), y[b == g]), (which, g)
+        assert seen == set(gids)
+    for g in gids:
+        assert res[0][3][g] == o.get_position(g) and res[1][3][g] == o.get_position(g)
+    assert res[0][4] > 0, "the scenario must force hand-overs"
+    assert res[0][5] != res[0][6], "ownership must have changed"
+    assert res[0][6] == res[1][6], "both ranks agree on who owns what"

@@ -54,7 +54,8 @@ struct EggStepArgs {
     int32_t lcap;      // visit-list entries per pass (capacity)
     int32_t spin_sleep;  // 1: idle waves of the pair dataflow sleep between polls (many tiles per CU)
     EggStatus *status;
-    unsigned char *scratch;  // egg_step_kernel_gl: n_tiles slices of egg_step_scratch_bytes()
+    unsigned char *scratch;  // egg_step_kernel_gl / _gs: n_tiles slices of scratch_stride bytes
+    unsigned long long scratch_stride;
 };
 
 #if defined(__HIPCC__)

@@ -24,6 +24,7 @@
 extern "C" __global__ void egg_step_kernel(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_occ(EggStepArgs A);
+extern "C" __global__ void egg_step_kernel_gs(EggStepArgs A);
 extern "C" __global__ void egg_selftest_arith_kernel(unsigned long long, int, unsigned long long *);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
                                                    int, double, int32_t *);
@@ -114,6 +115,8 @@ struct LaunchClass {  // tiles of similar size share a launch (uniform LDS geome
     int first_tile = 0, n_tiles = 0;
     int nmax = 0, amax = 0, ccap = 0, use_grid = 0, lcap = 0;
     int global_lists = 0;  // visit lists in the scratch buffer instead of LDS
+    int global_state = 0;  // everything in the scratch buffer (islands too large for LDS)
+    size_t scratch_stride = 0;
     size_t lds = 0, scratch_offset = 0;
 };
 
@@ -185,7 +188,8 @@ struct egg_handle {
     int opt_timing = 0;
     int opt_force_single = 0;
     int opt_spread = 1;
-    int opt_spin_sleep = -1;  // -1 auto  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
+    int opt_spin_sleep = -1;  // -1 auto
+    int opt_force_global_state = 0;  // test hook: run every tile through the global-memory-state kernel  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
     hipDeviceProp_t prop{};
     size_t lds_limit = 64 * 1024;  // dynamic LDS a step-kernel workgroup may use
 };
@@ -631,23 +635,35 @@ int retile(egg_handle *h, int which) {
         lcap = std::min<size_t>(lcap, kMaxListEntries);
         lcap = (lcap + 7) & ~(size_t)7;
         lc.lcap = (int)lcap;
-        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0,
-                                    egg_step_threads(lc.nmax, h->opt_spread));
-        if (lc.lds > h->lds_limit || lc.lds > 64 * 1024 || egg_step_threads(lc.nmax, h->opt_spread) > 256) {
+        const int threads = egg_step_threads(lc.nmax, h->opt_spread);
+        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0, threads);
+        bool want_global_state = h->opt_force_global_state != 0;
+        if (!want_global_state && (lc.lds > h->lds_limit || lc.lds > 64 * 1024 || threads > 256)) {
             // dense or large tiles: particle state stays in LDS, the visit lists go to global memory
             lc.global_lists = 1;
             lcap = std::max<size_t>({lcap, (size_t)(32.0 * lc.nmax), s.list_min});
             lcap = std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxListEntries);
             lc.lcap = (int)lcap;
-            lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1,
-                                        egg_step_threads(lc.nmax, h->opt_spread));
-            lc.scratch_offset = scratch_bytes;
-            scratch_bytes += (size_t)lc.n_tiles * egg_step_scratch_bytes(lc.lcap, single ? 1 : 0);
+            lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1, threads);
+            if (lc.lds > h->lds_limit) want_global_state = true;
         }
-        if (lc.lds > h->lds_limit)
-            return fail(h, EGG_ERR_UNSUPPORTED,
-                        "a tile of %d particles needs %zu bytes of LDS for its particle state (limit %zu)", lc.nmax,
-                        lc.lds, h->lds_limit);
+        if (want_global_state) {
+            // the particle state itself does not fit (a very large island): everything goes to the tile's
+            // scratch slice, laid out like the LDS image followed by the lists
+            lc.global_lists = lc.global_state = 1;
+            lcap = std::max<size_t>({lcap, (size_t)(32.0 * lc.nmax), s.list_min});
+            lc.lcap = (int)std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxListEntries);
+            const size_t state = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1, threads);
+            lc.scratch_stride = ((state + 255) & ~(size_t)255) + egg_step_scratch_bytes(lc.lcap, single ? 1 : 0) + 256;
+            lc.lds = 0;
+        } else if (lc.global_lists) {
+            lc.scratch_stride = (egg_step_scratch_bytes(lc.lcap, single ? 1 : 0) + 255) & ~(size_t)255;
+        }
+        if (lc.global_lists) {
+            scratch_bytes = (scratch_bytes + 255) & ~(size_t)255;
+            lc.scratch_offset = scratch_bytes;
+            scratch_bytes += (size_t)lc.n_tiles * lc.scratch_stride;
+        }
         s.classes.push_back(lc);
         t0 = t1;
     }
@@ -767,7 +783,11 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.spin_sleep = (h->opt_spin_sleep < 0) ? (lc.n_tiles > 2 * h->prop.multiProcessorCount ? 1 : 0) : h->opt_spin_sleep;
         A.status = s.d_status;
         A.scratch = s.d_scratch.p + lc.scratch_offset;
-        if (lc.global_lists)
+        A.scratch_stride = lc.scratch_stride;
+        if (lc.global_state)
+            hipLaunchKernelGGL(egg_step_kernel_gs, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
+                               64, s.stream, A);
+        else if (lc.global_lists)
             hipLaunchKernelGGL(egg_step_kernel_gl, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
                                lc.lds, s.stream, A);
         else if (lc.n_tiles >= 4 * h->prop.multiProcessorCount)  // throughput regime: residency over spill-freedom
@@ -1640,6 +1660,10 @@ int egg_set_option(egg_handle *h, int option, double value) {
         case EGG_OPT_THREADS_PER_PARTICLE:
             if (value != 1 && value != 2 && value != 4) return fail(h, EGG_ERR_INVALID_ARGUMENT, "threads per particle must be 1, 2 or 4");
             h->opt_spread = (int)value;
+            return EGG_OK;
+        case EGG_OPT_FORCE_GLOBAL_STATE:
+            h->opt_force_global_state = value != 0;
+            h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
             return EGG_OK;
         case EGG_OPT_BUDGET_PARTICLES_WHITE:
         case EGG_OPT_BUDGET_PARTICLES_YOLK:

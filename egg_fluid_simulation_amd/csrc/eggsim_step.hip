@@ -413,6 +413,7 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_
 // of the workgroup run ahead of each other freely.
 #define EGG_COMPILER_BARRIER() __asm__ volatile("" ::: "memory")
 
+template <bool GLOBAL_STATE>
 __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, int nthreads, double overlap,
                                        double compliance, double eps, int total, int spin_sleep,
                                        unsigned int &spins_out) {
@@ -449,6 +450,8 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
             const uint32_t da = __hip_atomic_load(&done[as], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t db = __hip_atomic_load(&done[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             EGG_COMPILER_BARRIER();  // counters first, then the data they guard
+            // global memory: no issue-order guarantee between waves -> a real acquire after the counters
+            if (GLOBAL_STATE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             double2 pa = t.pos[as];
             double2 pb = t.pos[b];
             const double2 wrb = t.wr[b];
@@ -463,6 +466,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
                     t.pos[b] = pb;
                 }
                 EGG_COMPILER_BARRIER();  // data first, then the counters that publish it
+                if (GLOBAL_STATE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __hip_atomic_store(&done[a], da + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_store(&done[b], db + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ++k;
@@ -484,7 +488,12 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
 // sequentially, and the pair scheduler prefetches its next entry, so HBM/L2 latency stays off
 // the critical path.  Dense tiles (several coincident batches) need this: their lists alone
 // exceed the LDS a workgroup may have.
-template <bool GLOBAL_LISTS>
+// GLOBAL_STATE = true (implies GLOBAL_LISTS): EVERYTHING except a few scalars lives in the tile's slice of
+// A.scratch.  This is the fallback for islands whose particle state does not fit into LDS: same
+// algorithm, HBM/L2 latency on every access, workgroup-scope release/acquire around the dataflow
+// counters (global memory gives no issue-order guarantee).  Slow, but any island up to the index
+// limits (32766 particles, 60000 visited pairs per pass) is stepped exactly.
+template <bool GLOBAL_LISTS, bool GLOBAL_STATE>
 __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -497,8 +506,8 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     // ---------------------------------------------------------------- LDS carve
     Tile t;
     {
-        unsigned char *p = smem;
         size_t n = (size_t)A.nmax, a = (size_t)A.amax, cc = (size_t)A.ccap, l = (size_t)A.lcap;
+        unsigned char *p = GLOBAL_STATE ? A.scratch + (size_t)tile * A.scratch_stride : smem;
         t.pos = (double2 *)carve(p, n * 16);
         t.wr = (double2 *)carve(p, n * 16);
         const bool state_in_lds = A.nmax > (int)blockDim.x;
@@ -524,7 +533,12 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
         t.aglob = (int32_t *)carve(p, a * 4);
         t.aaabb = (int32_t *)carve(p, a * 4 * 4);
         t.adisp = (int32_t *)carve(p, a * 4 * 4);
-        t.sc = (int32_t *)carve(p, 16 * 4);
+        __shared__ int32_t sc_lds[16];
+        if (GLOBAL_STATE) {
+            t.sc = sc_lds;
+        } else {
+            t.sc = (int32_t *)carve(p, 16 * 4);
+        }
         t.hitems_b = (uint16_t *)carve(p, 2 * n * 2);
         t.pslot = (uint16_t *)carve(p, n * 2);
         t.aslot = (uint16_t *)carve(p, n * 2);
@@ -532,7 +546,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
         if (!GLOBAL_LISTS) {
             t.own_ent_b = (uint16_t *)carve(p, A.single_tile ? 2 * l * 2 : 0);
         } else {
-            unsigned char *g = A.scratch + (size_t)tile * egg_step_scratch_bytes(A.lcap, A.single_tile);
+            unsigned char *g = GLOBAL_STATE ? p : A.scratch + (size_t)tile * A.scratch_stride;
             t.own_pack = (uint32_t *)g;
             t.inc_tmp = (uint32_t *)(g + egg_align16(l * 4));
             t.own_ent_b = (uint16_t *)(g + 2 * egg_align16(l * 4));
@@ -902,7 +916,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             PROF(6)  // transpose
             // -------------------------------------- dataflow execution of the pair projections
             unsigned int spins = 0;
-            int solved = execute_dataflow(t, cur, n, tid, nthreads, A.overlap_factor, A.collision_compliance, eps,
+            int solved = execute_dataflow<GLOBAL_STATE>(t, cur, n, tid, nthreads, A.overlap_factor, A.collision_compliance, eps,
                                           total, A.spin_sleep, spins);
             spins_total += spins;
             __syncthreads();
@@ -999,12 +1013,13 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
 }  // namespace
 
 // tiles of up to 256 particles (the common case): 4 waves, up to 512 registers per lane, no spills
-extern "C" __global__ void __launch_bounds__(256) egg_step_kernel(EggStepArgs A) { egg_step_body<false>(A); }
+extern "C" __global__ void __launch_bounds__(256) egg_step_kernel(EggStepArgs A) { egg_step_body<false, false>(A); }
 // the same with registers capped at 96 (5 waves per SIMD): when thousands of tiles queue for the
 // chip, six resident tiles per CU beat the spill-free build's four (measured: 2.75 -> 2.15 ms per
 // step at 4096 batches), while a tile that has its CU to itself is ~3 % slower
-extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_occ(EggStepArgs A) { egg_step_body<false>(A); }
-extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true>(A); }
+extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_occ(EggStepArgs A) { egg_step_body<false, false>(A); }
+extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true, false>(A); }
+extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs(EggStepArgs A) { egg_step_body<true, true>(A); }
 
 #ifdef EGG_PROFILE
 // developer microbenchmark (diagnostic build only): cycles per dependent projection of one wave,

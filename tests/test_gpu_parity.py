@@ -132,9 +132,9 @@ def test_result_is_independent_of_tiling(egg):
     """Tiles only decide which workgroup runs which particles: packing islands into shared tiles,
     wider claim margins or forcing a single tile must not change one bit."""
     from egg_fluid_simulation_amd import _ffi
-    xs, ys = _grid(6)  # 942 white particles: the forced single tile still fits in LDS
+    xs, ys = _grid(36)  # the forced single tile (5652 white particles) runs in the global-memory-state kernel
     ref = None
-    for opts in ({}, {_ffi.OPT_TILE_TARGET_PARTICLES: 500}, {_ffi.OPT_CLAIM_MARGIN_CELLS: 6},
+    for opts in ({}, {_ffi.OPT_TILE_TARGET_PARTICLES: 700}, {_ffi.OPT_CLAIM_MARGIN_CELLS: 6},
                  {_ffi.OPT_FORCE_SINGLE_TILE: 1}):
         h = egg.SimulationHandler()
         for k, v in opts.items():
@@ -147,9 +147,33 @@ def test_result_is_independent_of_tiling(egg):
         state = [h.download(w, f) for w in (WHITE, YOLK) for f in ("x", "y", "vx", "vy")]
         if ref is None:
             ref = state
-            assert h.stats()["n_tiles"][0] == 6
+            assert h.stats()["n_tiles"][0] == 36
         else:
             assert all(np.array_equal(a, b) for a, b in zip(ref, state)), opts
+
+
+def test_large_island_falls_back_to_global_memory_state(egg, oracle_mod):
+    """4 x 4 batches at 95 px pitch overlap into ONE island of 2512 white particles, far beyond what
+    fits in LDS.  The step kernel then keeps the tile's state in global memory; results stay exact.
+    (Index limits remain: 32766 particles and 60000 visited pairs per pass in one island.)"""
+    k = np.arange(16)
+    xs, ys = 500.0 + 95.0 * (k % 4), 500.0 + 95.0 * (k // 4)
+    h, o, _ = _run_both(egg, oracle_mod, xs, ys, 3, False)
+    _assert_same_state(h, o)
+    assert h.stats()["max_tile_particles"][0] == 16 * 157
+
+
+def test_global_memory_state_variant_on_ordinary_tiles(egg, oracle_mod):
+    """the same fallback kernel forced onto ordinary tiles (incl. the exact-budget yolk tile of a small
+    handler and a moving multi-batch case) must not change a bit"""
+    from egg_fluid_simulation_amd import _ffi
+    xs, ys = _grid(12, pitch=140.0)  # close enough to merge now and then
+    h, o, _ = _run_both(egg, oracle_mod, xs, ys, 10, True,
+                        configure=lambda hh: hh.set_option(_ffi.OPT_FORCE_GLOBAL_STATE, 1))
+    _assert_same_state(h, o)
+    h1, o1, _ = _run_both(egg, oracle_mod, np.array([400.0]), np.array([300.0]), 10, True,
+                          configure=lambda hh: hh.set_option(_ffi.OPT_FORCE_GLOBAL_STATE, 1))
+    _assert_same_state(h1, o1)
 
 
 def test_batches_that_merge_and_separate(egg, oracle_mod):

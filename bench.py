@@ -95,8 +95,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # "nccl" is RCCL on ROCm; EGG_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed with several
+        # ranks on ONE GPU (RCCL refuses duplicate devices)
+        backend = os.environ.get("EGG_BENCH_BACKEND", "nccl")
+        n_dev = max(1, torch.cuda.device_count())
+        local_rank = local_rank % n_dev
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group(backend)
 
     from egg_fluid_simulation_amd import WHITE, YOLK, SimulationHandler, _ffi
     from egg_fluid_simulation_amd.sharding import BoundaryExchange
@@ -111,9 +116,15 @@ def main():
                             slab_hi=100.0 + PITCH * (rank + 1) * side - PITCH / 2, group=dist) if world > 1 else None
 
     def one_step():
-        if halo is not None:
-            halo.exchange()  # neighbours' boundary batch boxes; asserts that no batch straddles a cut
-        h.step(1 / 60, 2, 3)
+        if halo is None:
+            h.step(1 / 60, 2, 3)
+            return
+        # neighbours' boundary-batch claims travel while the step kernels run; a conflict (a batch
+        # about to cross a cut) raises -- the tiled benchmark never produces one
+        halo.post()
+        h.step_begin(1 / 60, 2, 3)
+        halo.finish()
+        h.step_end(True)
 
     for _ in range(args.warmup):
         one_step()
@@ -138,10 +149,11 @@ def main():
     kernel_ms_white = s1["kernel_ms_sum"][WHITE] / max(1, s1["timed_steps"])
     kernel_ms_yolk = s1["kernel_ms_sum"][YOLK] / max(1, s1["timed_steps"])
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([pairs, follows, float(n_white + n_yolk)], dtype=torch.float64, device="cuda")
+        agg = torch.tensor([pairs, follows, float(n_white + n_yolk)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         pairs, follows, total_particles = (float(v) for v in agg.tolist())
     else:

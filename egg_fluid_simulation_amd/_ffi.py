@@ -82,10 +82,14 @@ _SIGNATURES = {
     "egg_get_target": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egg_update": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "egg_step": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
+    "egg_prepare_step": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
+    "egg_step_begin": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
+    "egg_step_end": (C.c_int, [C.c_void_p, C.c_int32]),
     "egg_synchronize": (C.c_int, [C.c_void_p]),
     "egg_get_position": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egg_get_positions_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egg_get_bounds_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "egg_get_claims_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "egg_get_n_particles": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "egg_list_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "egg_get_elapsed": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -192,6 +192,9 @@ struct egg_handle {
     int opt_force_global_state = 0;  // test hook: run every tile through the global-memory-state kernel  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
     hipDeviceProp_t prop{};
     size_t lds_limit = 64 * 1024;  // dynamic LDS a step-kernel workgroup may use
+    bool in_flight = false;        // egg_step_begin without its egg_step_end
+    double flight_delta = 0;
+    int flight_s = 0, flight_c = 0;
 };
 
 namespace {
@@ -812,45 +815,10 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     return EGG_OK;
 }
 
-int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
-    const double sub_delta = std::max(delta / S, h->sys[0].cfg.eps);
-    if (C == 1 && S >= 3)
-        return fail(h, EGG_ERR_UNSUPPORTED,
-                    "n_collision_steps == 1 with n_substeps >= 3 (hash lists accumulating over more than one "
-                    "un-cleared pass) is not implemented on the device path");
-    Env env[2];
+// atoms, targets and tiles (with the claims of the upcoming step) up to date on the host side
+int prepare_tiles(egg_handle *h) {
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];
-        env[w] = make_env(s.cfg, sub_delta, h->budget_particles[w] >= 0 ? h->budget_particles[w] : s.n);
-        // mass / radius follow a config change at the next step (L:1731-1744, L:1420-1430)
-        bool upd_mass = !s.has_env || s.cfg.min_mass != s.env_min_mass || s.cfg.max_mass != s.env_max_mass;
-        bool upd_radius = !s.has_env || s.cfg.min_radius != s.env_min_radius || s.cfg.max_radius != s.env_max_radius;
-        if (s.has_env && (upd_mass || upd_radius) && s.n > 0) {
-            const int threads = 256;
-            hipLaunchKernelGGL(egg_rederive_kernel, dim3((unsigned)((s.n + threads - 1) / threads)), dim3(threads), 0,
-                               s.stream, s.mass_t.p, s.inv_mass.p, s.radius.p, (int)s.n, upd_mass ? 1 : 0,
-                               s.cfg.min_mass, s.cfg.max_mass, upd_radius ? 1 : 0, s.cfg.min_radius, s.cfg.max_radius);
-            HIP_TRY(h, hipGetLastError());
-            h->stats.kernel_launches++;
-        }
-        s.has_env = true;
-        s.env_min_mass = s.cfg.min_mass;
-        s.env_max_mass = s.cfg.max_mass;
-        s.env_min_radius = s.cfg.min_radius;
-        s.env_max_radius = s.cfg.max_radius;
-        if (env[w].cell != s.tiled_cell_size) {
-            s.tiling_dirty = true;
-            s.aabb_valid = false;
-        }
-        s.step_follow_compliance = env[w].follow_c;
-        s.step_damping = env[w].damping;
-        s.step_substeps = S;
-    }
-
-    for (int attempt = 0;; ++attempt) {
-        if (attempt > 24) return fail(h, EGG_ERR_INTERNAL, "step did not validate after %d attempts", attempt);
-        for (int w = 0; w < 2; ++w) {
-            System &s = h->sys[w];
             int rc = upload_atoms(h, w);
             if (rc != EGG_OK) return rc;
             if (s.claims_stale && !s.tiling_dirty) {
@@ -877,9 +845,59 @@ int do_step(egg_handle *h, double delta, int S, int C) {  // L:1722-1989
                 if (rc != EGG_OK) return rc;
             }
         }
-        for (int w = 0; w < 2; ++w) {
-            int rc = launch_type(h, w, env[w], S, C);
+    return EGG_OK;
+}
+
+// phase: kWhole = the complete step; kPrepare = tiles/claims only; kBegin = launch the first attempt and
+// return (egg_step_begin); kEnd = finish a begun step: validate, re-run if needed, commit (egg_step_end)
+enum { kWhole = 0, kPrepare = 1, kBegin = 2, kEnd = 3 };
+
+int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  // L:1722-1989
+    const double sub_delta = std::max(delta / S, h->sys[0].cfg.eps);
+    if (C == 1 && S >= 3)
+        return fail(h, EGG_ERR_UNSUPPORTED,
+                    "n_collision_steps == 1 with n_substeps >= 3 (hash lists accumulating over more than one "
+                    "un-cleared pass) is not implemented on the device path");
+    Env env[2];
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        env[w] = make_env(s.cfg, sub_delta, h->budget_particles[w] >= 0 ? h->budget_particles[w] : s.n);
+        // mass / radius follow a config change at the next step (L:1731-1744, L:1420-1430)
+        bool upd_mass = !s.has_env || s.cfg.min_mass != s.env_min_mass || s.cfg.max_mass != s.env_max_mass;
+        bool upd_radius = !s.has_env || s.cfg.min_radius != s.env_min_radius || s.cfg.max_radius != s.env_max_radius;
+        if (phase != kEnd && s.has_env && (upd_mass || upd_radius) && s.n > 0) {
+            const int threads = 256;
+            hipLaunchKernelGGL(egg_rederive_kernel, dim3((unsigned)((s.n + threads - 1) / threads)), dim3(threads), 0,
+                               s.stream, s.mass_t.p, s.inv_mass.p, s.radius.p, (int)s.n, upd_mass ? 1 : 0,
+                               s.cfg.min_mass, s.cfg.max_mass, upd_radius ? 1 : 0, s.cfg.min_radius, s.cfg.max_radius);
+            HIP_TRY(h, hipGetLastError());
+            h->stats.kernel_launches++;
+        }
+        s.has_env = true;
+        s.env_min_mass = s.cfg.min_mass;
+        s.env_max_mass = s.cfg.max_mass;
+        s.env_min_radius = s.cfg.min_radius;
+        s.env_max_radius = s.cfg.max_radius;
+        if (env[w].cell != s.tiled_cell_size) {
+            s.tiling_dirty = true;
+            s.aabb_valid = false;
+        }
+        s.step_follow_compliance = env[w].follow_c;
+        s.step_damping = env[w].damping;
+        s.step_substeps = S;
+    }
+    if (phase == kPrepare) return prepare_tiles(h);
+
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 24) return fail(h, EGG_ERR_INTERNAL, "step did not validate after %d attempts", attempt);
+        if (!(phase == kEnd && attempt == 0)) {  // kEnd: the first attempt is already in flight
+            int rc = prepare_tiles(h);
             if (rc != EGG_OK) return rc;
+            for (int w = 0; w < 2; ++w) {
+                rc = launch_type(h, w, env[w], S, C);
+                if (rc != EGG_OK) return rc;
+            }
+            if (phase == kBegin) return EGG_OK;
         }
         bool redo = false;
         double ms = 0;
@@ -1351,6 +1369,43 @@ int egg_update(egg_handle *h, double delta, double step_delta, int32_t n_substep
     return EGG_OK;
 }
 
+int egg_prepare_step(egg_handle *h, double step_delta, int32_t n_substeps, int32_t n_collision_steps) {
+    if (!h || n_substeps < 1 || n_collision_steps < 1 || !(step_delta >= 0)) return EGG_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(h->device);
+    return do_step(h, step_delta, n_substeps, n_collision_steps, kPrepare);
+}
+
+int egg_step_begin(egg_handle *h, double delta, int32_t n_substeps, int32_t n_collision_steps) {
+    if (!h || n_substeps < 1 || n_collision_steps < 1 || std::isnan(delta)) return EGG_ERR_INVALID_ARGUMENT;
+    if (h->in_flight) return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_step_begin: a step is already in flight");
+    (void)hipSetDevice(h->device);
+    int rc = do_step(h, delta, n_substeps, n_collision_steps, kBegin);
+    if (rc == EGG_OK) {
+        h->in_flight = true;
+        h->flight_delta = delta;
+        h->flight_s = n_substeps;
+        h->flight_c = n_collision_steps;
+    }
+    return rc;
+}
+
+int egg_step_end(egg_handle *h, int32_t commit) {
+    if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    if (!h->in_flight) return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_step_end: no step in flight");
+    (void)hipSetDevice(h->device);
+    h->in_flight = false;
+    if (!commit) {
+        // discard: the launches wrote the inactive buffers only; wait for them and forget
+        for (int w = 0; w < 2; ++w) {
+            HIP_TRY(h, hipStreamSynchronize(h->sys[w].stream));
+            h->sys[w].aabb_on_device = false;
+            h->sys[w].out_copied = false;
+        }
+        return EGG_OK;
+    }
+    return do_step(h, h->flight_delta, h->flight_s, h->flight_c, kEnd);
+}
+
 int egg_synchronize(egg_handle *h) {
     if (!h) return EGG_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(h->device);
@@ -1443,11 +1498,41 @@ int egg_get_bounds_many(egg_handle *h, int64_t n, const int64_t *ids, double *lo
         if (!find_batch(h, ids[k]))
             return fail(h, EGG_ERR_UNKNOWN_ID, "egg_get_bounds_many: no batch with id `%lld`", (long long)ids[k]);
         const int32_t a = atom_of_batch[(size_t)ids[k] - 1];
-        const Box &bw = h->sys[0].aabb[(size_t)a], &by = h->sys[1].aabb[(size_t)a];
+        // the claim of the upcoming step when the tiles are current (egg_prepare_step), else the occupied cells
+        const System &sw = h->sys[0], &sy = h->sys[1];
+        const bool cw = !sw.tiling_dirty && sw.h_claim.size() == sw.atoms.size();
+        const bool cy = !sy.tiling_dirty && sy.h_claim.size() == sy.atoms.size();
+        const Box &bw = cw ? sw.h_claim[(size_t)a] : sw.aabb[(size_t)a], &by = cy ? sy.h_claim[(size_t)a] : sy.aabb[(size_t)a];
         lo_x[k] = std::min(bw.lo_x * cell[0], by.lo_x * cell[1]);
         lo_y[k] = std::min(bw.lo_y * cell[0], by.lo_y * cell[1]);
         hi_x[k] = std::max((bw.hi_x + 1.0) * cell[0], (by.hi_x + 1.0) * cell[1]);
         hi_y[k] = std::max((bw.hi_y + 1.0) * cell[0], (by.hi_y + 1.0) * cell[1]);
+    }
+    return EGG_OK;
+}
+
+int egg_get_claims_many(egg_handle *h, int64_t n, const int64_t *ids, double *boxes, double *cell_sizes) {
+    if (!h || n < 0 || (n > 0 && (!ids || !boxes))) return EGG_ERR_INVALID_ARGUMENT;
+    std::vector<double> lx((size_t)n), ly((size_t)n), hx((size_t)n), hy((size_t)n);
+    // reuse the bounds path to make sure boxes / claims are current
+    int rc = egg_get_bounds_many(h, n, ids, lx.data(), ly.data(), hx.data(), hy.data());
+    if (rc != EGG_OK) return rc;
+    std::vector<int32_t> atom_of_batch(h->batches.size(), -1);
+    for (size_t k = 0; k < h->sys[0].atoms.size(); ++k) atom_of_batch[(size_t)h->sys[0].atoms[k].batch] = (int32_t)k;
+    for (int w = 0; w < 2; ++w) {
+        const System &s = h->sys[w];
+        const double cell = cell_size_of(s.cfg);
+        if (cell_sizes) cell_sizes[w] = cell;
+        const bool claims = !s.tiling_dirty && s.h_claim.size() == s.atoms.size();
+        for (int64_t k = 0; k < n; ++k) {
+            const int32_t a = atom_of_batch[(size_t)ids[k] - 1];
+            const Box &b = claims ? s.h_claim[(size_t)a] : s.aabb[(size_t)a];
+            double *o = boxes + 8 * k + 4 * w;
+            o[0] = b.lo_x * cell;
+            o[1] = b.lo_y * cell;
+            o[2] = (b.hi_x + 1.0) * cell;
+            o[3] = (b.hi_y + 1.0) * cell;
+        }
     }
     return EGG_OK;
 }

@@ -60,18 +60,25 @@ class SlabLayout:
 class BoundaryExchange:
     """Per-step exchange of slab-boundary batch boxes with the left and right neighbour rank.
 
+    The exchanged boxes are the batches' CLAIMS for the upcoming step (SimulationHandler.prepare_step +
+    get_bounds): two batches on different ranks are independent iff their claims stay at least one
+    spatial-hash cell apart -- the same criterion that separates tiles inside one handler.
+    Boxes are [n, 8]: the white claim then the yolk claim; interact_px = (white cell, yolk cell).
+
     handler      SimulationHandler of this rank, or None when `bounds_fn` is given
     bounds_fn    () -> (ids[n] int64, boxes[n, 4] float64 px) of the local batches (tests inject this)
     group        a torch.distributed module/process group handle (None: world must be 1)
     """
 
-    RECORD = 5  # id, lo_x, lo_y, hi_x, hi_y
+    RECORD = 9  # id, white box (lo_x, lo_y, hi_x, hi_y), yolk box
 
-    def __init__(self, handler, rank, world, slab_lo, slab_hi, group=None, halo_px=64.0, interact_px=48.0,
+    def __init__(self, handler, rank, world, slab_lo, slab_hi, group=None, halo_px=64.0, interact_px=(8.0, 12.0),
                  capacity=4096, bounds_fn=None, device=None):
         self.handler, self.rank, self.world = handler, int(rank), int(world)
         self.slab_lo, self.slab_hi = float(slab_lo), float(slab_hi)
-        self.halo_px, self.interact_px, self.capacity = float(halo_px), float(interact_px), int(capacity)
+        if np.isscalar(interact_px):
+            interact_px = (interact_px, interact_px)
+        self.halo_px, self.interact_px, self.capacity = float(halo_px), tuple(float(v) for v in interact_px), int(capacity)
         self.dist = group
         self.bounds_fn = bounds_fn or self._handler_bounds
         self.ghosts = {}          # neighbour rank -> (ids, boxes) received in the last exchange
@@ -86,72 +93,122 @@ class BoundaryExchange:
             n = 1 + self.RECORD * self.capacity
             self._send = {r: torch.zeros(n, dtype=torch.float64, device=device) for r in self._neighbours()}
             self._recv = {r: torch.zeros(n, dtype=torch.float64, device=device) for r in self._neighbours()}
+            # host images of the messages (pinned when the wire tensors live on the GPU): no per-step
+            # allocation, one async copy each way
+            pin = str(device).startswith("cuda")
+            self._send_host = {r: torch.zeros(n, dtype=torch.float64, pin_memory=pin) for r in self._neighbours()}
+            self._recv_host = {r: torch.zeros(n, dtype=torch.float64, pin_memory=pin) for r in self._neighbours()}
 
     def _neighbours(self):
         return [r for r in (self.rank - 1, self.rank + 1) if 0 <= r < self.world]
 
     def _handler_bounds(self):
+        self.handler.prepare_step()
         ids = np.asarray(self.handler.list_ids(), dtype=np.int64)
-        return ids, self.handler.get_bounds(ids)
+        boxes, cells = self.handler.get_claims(ids)
+        self.interact_px = cells
+        return ids, boxes
 
     def select_boundary(self, ids, boxes, towards):
         """local batches within halo_px of the cut shared with rank `towards`"""
         if towards < self.rank:
-            m = boxes[:, 0] < self.slab_lo + self.halo_px
+            m = np.minimum(boxes[:, 0], boxes[:, 4]) < self.slab_lo + self.halo_px
         else:
-            m = boxes[:, 2] > self.slab_hi - self.halo_px
+            m = np.maximum(boxes[:, 2], boxes[:, 6]) > self.slab_hi - self.halo_px
         return ids[m], boxes[m]
 
     @staticmethod
     def conflicts(ids, boxes, ghost_ids, ghost_boxes, reach):
-        """pairs (local id, ghost id) whose boxes come within `reach` px of each other"""
-        out = []
-        for gid, g in zip(ghost_ids, ghost_boxes):
-            near = ((boxes[:, 0] <= g[2] + reach) & (g[0] <= boxes[:, 2] + reach) &
-                    (boxes[:, 1] <= g[3] + reach) & (g[1] <= boxes[:, 3] + reach))
-            out += [(int(i), int(gid)) for i in ids[near]]
-        return out
-
-    def exchange(self, raise_on_conflict=True):
-        """Swap boundary boxes with both neighbours.  Returns the conflicts found as
-        (local id, ghost id, ghost rank); raises SlabConflict for them unless told otherwise."""
-        if self.world == 1:
+        """pairs (local id, ghost id) whose claims are LESS than one hash cell apart in both x and y, for
+        the white boxes (columns 0-3, cell reach[0]) or the yolk boxes (columns 4-7, cell reach[1])"""
+        if np.isscalar(reach):
+            reach = (reach, reach)
+        if len(ids) == 0 or len(ghost_ids) == 0:
             return []
+        boxes = np.asarray(boxes, dtype=np.float64).reshape(len(ids), -1)
+        ghost_boxes = np.asarray(ghost_boxes, dtype=np.float64).reshape(len(ghost_ids), -1)
+        if boxes.shape[1] == 4:  # one box per batch: use it for both types
+            boxes = np.concatenate([boxes, boxes], axis=1)
+        if ghost_boxes.shape[1] == 4:
+            ghost_boxes = np.concatenate([ghost_boxes, ghost_boxes], axis=1)
+        ids = np.asarray(ids)
+        ghost_ids = np.asarray(ghost_ids)
+        near = np.zeros((len(ids), len(ghost_ids)), dtype=bool)
+        for t in (0, 1):
+            b, g, c = boxes[:, None, 4 * t:4 * t + 4], ghost_boxes[None, :, 4 * t:4 * t + 4], reach[t]
+            near |= ((b[..., 0] - g[..., 2] < c) & (g[..., 0] - b[..., 2] < c) &
+                     (b[..., 1] - g[..., 3] < c) & (g[..., 1] - b[..., 3] < c))
+        li, gi = np.nonzero(near.T)[::-1]
+        return [(int(ids[a]), int(ghost_ids[b_])) for a, b_ in zip(li, gi)]
+
+    def post(self):
+        """First half of the exchange: collect this rank's claims and start the sends / receives."""
+        if self.world == 1:
+            return
         torch, dist = self.torch, self.dist
         ids, boxes = self.bounds_fn()
         ids = np.asarray(ids, dtype=np.int64)
-        boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
-        outside = (boxes[:, 0] < self.slab_lo - self.interact_px) | (boxes[:, 2] > self.slab_hi + self.interact_px)
+        boxes = np.asarray(boxes, dtype=np.float64).reshape(len(ids), -1) if len(ids) else np.zeros((0, 8))
+        if boxes.shape[1] == 4:
+            boxes = np.concatenate([boxes, boxes], axis=1)
         ops = []
         for r in self._neighbours():
             bi, bb = self.select_boundary(ids, boxes, r)
             if len(bi) > self.capacity:
                 raise RuntimeError("more than %d boundary batches; raise BoundaryExchange(capacity=...)" % self.capacity)
-            rec = np.zeros(1 + self.RECORD * self.capacity)
+            rec = self._send_host[r].numpy()
             rec[0] = len(bi)
-            rec[1:1 + self.RECORD * len(bi)] = np.concatenate([bi[:, None].astype(np.float64), bb], axis=1).ravel()
-            self._send[r].copy_(torch.from_numpy(rec))
+            body = rec[1:1 + self.RECORD * len(bi)].reshape(len(bi), self.RECORD)
+            body[:, 0] = bi
+            body[:, 1:] = bb
+            if self._send[r].data_ptr() != self._send_host[r].data_ptr():
+                self._send[r].copy_(self._send_host[r], non_blocking=True)
             self.sent[r] = len(bi)
             ops.append(dist.P2POp(dist.isend, self._send[r], r))
             ops.append(dist.P2POp(dist.irecv, self._recv[r], r))
-        for req in dist.batch_isend_irecv(ops):
+        self._pending = dist.batch_isend_irecv(ops)
+        self.last_ids, self.last_boxes = ids, boxes
+
+    def finish(self, raise_on_conflict=True):
+        """Second half: wait for the neighbours' claims and test them against the local ones.  Returns
+        the conflicts as (local id, ghost id, ghost rank); raises SlabConflict for them unless told
+        otherwise."""
+        if self.world == 1:
+            return []
+        for req in self._pending:
             req.wait()
+        self._pending = []
+        ids, boxes = self.last_ids, self.last_boxes
         found = []
         for r in self._neighbours():
-            rec = self._recv[r].cpu().numpy()
+            self._recv_host[r].copy_(self._recv[r])
+            rec = self._recv_host[r].numpy()
             n = int(rec[0])
             body = rec[1:1 + self.RECORD * n].reshape(n, self.RECORD)
-            gids, gboxes = body[:, 0].astype(np.int64), body[:, 1:]
+            gids, gboxes = body[:, 0].astype(np.int64), body[:, 1:].copy()
             self.ghosts[r] = (gids, gboxes)
             self.bytes_exchanged += 8 * (2 + self.RECORD * (n + self.sent[r]))
-            found += [(i, g, r) for i, g in self.conflicts(ids, boxes, gids, gboxes, self.interact_px)]
-        self.last_ids, self.last_boxes = ids, boxes
-        if raise_on_conflict and (found or outside.any()):
+            if n:
+                # only local batches that reach as far towards that cut as the ghosts reach into this slab
+                # (at least the halo) can meet them
+                c = max(self.interact_px)
+                if r < self.rank:
+                    depth = max(self.halo_px, float(np.max(gboxes[:, [2, 6]])) - self.slab_lo + c)
+                    m = np.minimum(boxes[:, 0], boxes[:, 4]) < self.slab_lo + depth
+                else:
+                    depth = max(self.halo_px, self.slab_hi - float(np.min(gboxes[:, [0, 4]])) + c)
+                    m = np.maximum(boxes[:, 2], boxes[:, 6]) > self.slab_hi - depth
+                found += [(i, g, r) for i, g in self.conflicts(ids[m], boxes[m], gids, gboxes, self.interact_px)]
+        if raise_on_conflict and found:
             raise SlabConflict(
-                "rank %d: %d local/ghost batch pairs within %.0f px across a slab cut (first: %s), %d local batches "
-                "outside their slab; handing batches over between ranks is not implemented"
-                % (self.rank, len(found), self.interact_px, found[:1], int(outside.sum())))
+                "rank %d: %d local/ghost batch pairs less than one hash cell apart across a slab cut (first: %s); "
+                "use ShardedSimulationHandler to hand such batches over" % (self.rank, len(found), found[:1]))
         return found
+
+    def exchange(self, raise_on_conflict=True):
+        """post() + finish()"""
+        self.post()
+        return self.finish(raise_on_conflict)
 
 
 class ShardedSimulationHandler:
@@ -164,7 +221,7 @@ class ShardedSimulationHandler:
 
     STATE_FIELDS = 9
 
-    def __init__(self, layout, rank, group, make_handler, halo_px=64.0, interact_px=48.0, device=None):
+    def __init__(self, layout, rank, group, make_handler, halo_px=64.0, interact_px=(8.0, 12.0), device=None):
         import torch
         self.torch, self.dist = torch, group
         self.layout, self.rank, self.world = layout, int(rank), layout.world
@@ -175,6 +232,7 @@ class ShardedSimulationHandler:
         self.radii = {}       # global id -> (white_radius, yolk_radius)
         self.next_gid = 1
         self.migrations = 0
+        self._step_args = (1 / 60, 2, 3)
         lo, hi = layout.bounds(rank)
         self.exchange = BoundaryExchange(None, rank, self.world, lo, hi, group=group, halo_px=halo_px,
                                          interact_px=interact_px, bounds_fn=self._bounds, device=device)
@@ -199,8 +257,33 @@ class ShardedSimulationHandler:
             self.local.set_target_position(self.local_id[gid], x, y)
 
     def update(self, delta, step_delta=None, n_substeps=None, n_collision_steps=None):
+        self._step_args = (1 / 60 if step_delta is None else step_delta, 2 if n_substeps is None else n_substeps,
+                           3 if n_collision_steps is None else n_collision_steps)
         self.rebalance()
         return self.local.update(delta, step_delta, n_substeps, n_collision_steps)
+
+    def step(self, delta=1 / 60, n_substeps=2, n_collision_steps=3):
+        """One `_step` on every rank with the neighbour exchange hidden behind the kernels: post the
+        claims, launch the local step, then look at the neighbours' claims; only if some pair of batches
+        on different ranks could interact is the launched step discarded, the batches handed over and
+        the step run again."""
+        self._step_args = (delta, n_substeps, n_collision_steps)
+        if self.world == 1:
+            self.local.step(delta, n_substeps, n_collision_steps)
+            return 0
+        self.exchange.post()
+        self.local.step_begin(delta, n_substeps, n_collision_steps)
+        conflicts = self.exchange.finish(raise_on_conflict=False)
+        # strays (batches deep inside another slab) are balanced too, but never force a re-run by themselves
+        flag = self.torch.tensor([1.0 if conflicts else 0.0], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        if float(flag.item()) == 0.0:
+            self.local.step_end(True)
+            return 0
+        self.local.step_end(False)
+        moved = self.rebalance()
+        self.local.step(delta, n_substeps, n_collision_steps)
+        return moved
 
     def positions(self):
         """{global id: (x, y)} of every batch, gathered on all ranks"""
@@ -221,10 +304,13 @@ class ShardedSimulationHandler:
 
     # ------------------------------------------------------------ internals
     def _bounds(self):
+        self.local.prepare_step(*self._step_args)
         gids = np.array(sorted(self.local_id), dtype=np.int64)
         if len(gids) == 0:
-            return gids, np.zeros((0, 4))
-        return gids, self.local.get_bounds([self.local_id[int(g)] for g in gids])
+            return gids, np.zeros((0, 8))
+        boxes, cells = self.local.get_claims([self.local_id[int(g)] for g in gids])
+        self.exchange.interact_px = cells
+        return gids, boxes
 
     def _sync_budget(self):
         # the budget 0.05 N^2 counts the particles of ALL ranks (simulation_handler.lua:1752-1753)
@@ -289,9 +375,9 @@ class ShardedSimulationHandler:
                 g = int(g)
                 if g in in_conflict:
                     continue
-                if self.rank > 0 and b[2] < lo - self.exchange.halo_px:
+                if self.rank > 0 and max(b[2], b[6]) < lo - self.exchange.halo_px:
                     to_left.add(g)
-                elif self.rank + 1 < self.world and b[0] > hi + self.exchange.halo_px:
+                elif self.rank + 1 < self.world and min(b[0], b[4]) > hi + self.exchange.halo_px:
                     to_right.add(g)
             # everyone learns every plan: how many batches arrive from whom, and the new owner table
             gathered = [None] * self.world

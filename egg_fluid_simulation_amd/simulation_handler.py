@@ -303,6 +303,17 @@ class SimulationHandler:
         """`_step` directly (L:1722); not part of the reference's public surface."""
         self._check(self._lib.egg_step(self._h, float(delta), int(n_substeps), int(n_collision_steps)))
 
+    def step_begin(self, delta=1 / 60, n_substeps=2, n_collision_steps=3):
+        """launch a `_step` without waiting for it (see egg_step_begin)"""
+        self._check(self._lib.egg_step_begin(self._h, float(delta), int(n_substeps), int(n_collision_steps)))
+
+    def step_end(self, commit=True):
+        self._check(self._lib.egg_step_end(self._h, 1 if commit else 0))
+
+    def prepare_step(self, step_delta=1 / 60, n_substeps=2, n_collision_steps=3):
+        """form the tiles/claims of the next step without running it (multi-GPU exchange)"""
+        self._check(self._lib.egg_prepare_step(self._h, float(step_delta), int(n_substeps), int(n_collision_steps)))
+
     # ---------------------------------------------------------------- targets
     def set_target_position(self, batch_id, x, y):  # L:254-264
         _assert_types(batch_id, "number", x, "number", y, "number")
@@ -342,6 +353,14 @@ class SimulationHandler:
         self._check(self._lib.egg_get_bounds_many(self._h, ids.shape[0], ids.ctypes.data, out[0].ctypes.data,
                                                   out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data))
         return out.T.copy()
+
+    def get_claims(self, ids):
+        """([n, 8] array: white box then yolk box, lo_x lo_y hi_x hi_y in px; (white cell, yolk cell))"""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.empty((ids.shape[0], 8), dtype=np.float64)
+        cells = np.empty(2, dtype=np.float64)
+        self._check(self._lib.egg_get_claims_many(self._h, ids.shape[0], ids.ctypes.data, out.ctypes.data, cells.ctypes.data))
+        return out, (float(cells[0]), float(cells[1]))
 
     # ----------------------------------------------------------------- colors
     # render attributes: kept on the host, never read by the solver (L:297-395)

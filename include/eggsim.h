@@ -122,6 +122,16 @@ int egg_update(egg_handle *h, double delta, double step_delta, int32_t n_substep
                int32_t n_collision_steps, int32_t *out_n_steps);
 /* _step(delta, n_sub_steps, n_collision_steps) directly (L:1722) */
 int egg_step(egg_handle *h, double delta, int32_t n_substeps, int32_t n_collision_steps);
+/* Forms the tiles and claims the next _step(step_delta, n_substeps, n_collision_steps) will use, without
+ * running it.  Multi-GPU: egg_get_bounds_many then returns each batch's CLAIM for that step, which
+ * neighbouring ranks exchange to decide whether two batches on different ranks could interact. */
+int egg_prepare_step(egg_handle *h, double step_delta, int32_t n_substeps, int32_t n_collision_steps);
+/* A _step in two halves, so that a caller can overlap its own work (the multi-GPU neighbour exchange)
+ * with the kernels: egg_step_begin forms the tiles and launches; egg_step_end(commit = 1) waits,
+ * validates, re-runs if needed and commits -- begin + end(1) == egg_step; egg_step_end(commit = 0)
+ * discards the launched step (the state is double-buffered, nothing was committed). */
+int egg_step_begin(egg_handle *h, double delta, int32_t n_substeps, int32_t n_collision_steps);
+int egg_step_end(egg_handle *h, int32_t commit);
 /* blocks until all device work of this handle is finished */
 int egg_synchronize(egg_handle *h);
 
@@ -129,11 +139,18 @@ int egg_synchronize(egg_handle *h);
 int egg_get_position(egg_handle *h, int64_t id, double *x, double *y);
 int egg_get_positions_many(egg_handle *h, int64_t n, const int64_t *ids, double *xs, double *ys);
 
-/* axis-aligned bounds (px) of each batch's particles, white and yolk together, rounded outwards to
- * the spatial-hash cells they occupy (L:1494-1495).  Used by the multi-GPU slab exchange; the
+/* axis-aligned bounds (px) of each batch, white and yolk together: the cells the batch CLAIMS for the
+ * upcoming step when the tiles are current (after egg_prepare_step), otherwise the spatial-hash cells
+ * its particles occupy (L:1494-1495).  Used by the multi-GPU slab exchange; the
  * reference computes the same per-environment AABB in _post_solve (L:1703-1709). */
 int egg_get_bounds_many(egg_handle *h, int64_t n, const int64_t *ids, double *lo_x, double *lo_y,
                         double *hi_x, double *hi_y);
+
+/* per type: boxes[8 * k + 4 * type + {0,1,2,3}] = lo_x, lo_y, hi_x, hi_y (px) of batch k's claim for the
+ * upcoming step (occupied cells if the tiles are not current); cell_sizes[type] = that type's hash cell.
+ * Batches of different handlers are independent iff, for both types, their boxes are at least one cell
+ * of that type apart in x or in y -- the criterion that separates tiles inside one handler. */
+int egg_get_claims_many(egg_handle *h, int64_t n, const int64_t *ids, double *boxes, double *cell_sizes);
 
 /* get_n_particles(id) / get_n_particles() with id < 0 (L:409-419) */
 int egg_get_n_particles(const egg_handle *h, int64_t id, int64_t *n_white, int64_t *n_yolk);

@@ -25,5 +25,6 @@ def run(nb, steps=50, warm=10, pack=0):
     sys.stdout.flush()
 
 if __name__ == "__main__":
+    pack = int(os.environ.get('EGG_PACK', '0'))
     for nb in [int(a) for a in sys.argv[1:]] or [1, 16, 256, 1024, 4096]:
-        run(nb)
+        run(nb, pack=pack)

@@ -54,7 +54,10 @@ def _worker(rank, world, port, q):
         for k in range(N_STEPS):
             for g in gids:
                 sh.set_target_position(g, *target(g, k))
-            assert sh.update(1 / 60) == 1
+            if k % 2 == 0:
+                sh.step(1 / 60)  # exchange overlapped with the kernels, re-run after a hand-over
+            else:
+                assert sh.update(1 / 60) == 1  # exchange and hand-over first, then the step
         white = {g: (x.tolist(), y.tolist()) for g, (x, y) in sh.particles(0).items()}
         yolk = {g: (x.tolist(), y.tolist()) for g, (x, y) in sh.particles(1).items()}
         pos = sh.positions()

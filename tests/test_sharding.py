@@ -65,6 +65,9 @@ def _worker(rank, world, port, scenario, q):
             outcome = "conflict"
         ghosts = {r: (g[0].tolist(), g[1].tolist()) for r, g in ex.ghosts.items()}
         q.put((rank, outcome, ghosts, dict(ex.sent)))
+    except Exception:  # surface the traceback in the parent instead of a queue timeout
+        import traceback
+        q.put((rank, "error: " + traceback.format_exc(), {}, {}))
     finally:
         dist.destroy_process_group()
 
@@ -81,6 +84,7 @@ def test_boundary_exchange_two_ranks_gloo(scenario):
     res = {}
     for _ in procs:
         rank, outcome, ghosts, sent = q.get(timeout=120)
+        assert not outcome.startswith("error"), outcome
         res[rank] = (outcome, ghosts, sent)
     for p in procs:
         p.join(60)
@@ -94,4 +98,4 @@ def test_boundary_exchange_two_ranks_gloo(scenario):
         # each rank learns about the other's boundary batch and both flag the same pair
         assert res[0][0] == res[1][0] == "conflict"
         assert res[0][1][1][0] == [100] and res[1][1][0][0] == [3]
-        assert res[0][1][1][1][0][0] == pytest.approx(1000.0 + 40 - 56)
+        assert res[0][1][1][1][0][0] == pytest.approx(1000.0 + 40 - 56)  # white box lo_x of the ghost

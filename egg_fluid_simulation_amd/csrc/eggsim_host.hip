@@ -975,7 +975,13 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
             const EggStatus &st = *s.h_status;
             s.cur ^= 1;
             const int np = std::min(S * C, EGG_MAX_PASSES);
-            for (int p = 0; p < np; ++p) h->stats.pair_solves += (int64_t)st.visits[p];
+            int64_t most = 0;
+            for (int p = 0; p < np; ++p) {
+                h->stats.pair_solves += (int64_t)st.visits[p];
+                most = std::max(most, (int64_t)st.visits[p]);
+            }
+            h->stats.max_pass_visits[w] = most;
+            h->stats.budget[w] = env[w].budget;
             h->stats.follow_solves += s.n * S;
             s.aabb_on_device = true;  // d_atom_aabb now holds end-of-step cells
             if (s.out_copied) {

@@ -22,11 +22,15 @@ batches that provably cannot interact.  Sharding therefore works on whole batche
     raises SlabConflict instead of migrating.
 
 Not covered: the collision budget's exact-mode (a type with so few particles that 0.05 N^2 visits
-can bind) needs all particles in one tile and therefore on one rank.
+can bind) needs all particles in one tile and therefore on one rank.  ShardedSimulationHandler.step
+watches for it (per-pass visits summed over ranks against the global budget) and raises EggError
+instead of stepping on.
 """
 import math
 
 import numpy as np
+
+from .simulation_handler import EggError
 
 
 class SlabConflict(RuntimeError):
@@ -274,10 +278,30 @@ class ShardedSimulationHandler:
         self.exchange.post()
         self.local.step_begin(delta, n_substeps, n_collision_steps)
         conflicts = self.exchange.finish(raise_on_conflict=False)
-        # strays (batches deep inside another slab) are balanced too, but never force a re-run by themselves
-        flag = self.torch.tensor([1.0 if conflicts else 0.0], dtype=self.torch.float64, device=self.device)
+        # strays (batches deep inside another slab) are balanced too, but never force a re-run by themselves.
+        # The second flag guards the collision budget (simulation_handler.lua:1657-1658): the reference
+        # counts the visits of ALL particles against 0.05 N^2, a rank only sees its own.  While every rank
+        # stays below budget / world the global count cannot bind; a rank above it (seen in the previous
+        # step) triggers the exact sum, and a binding budget across ranks is refused loudly.
+        st = self.local.stats()
+        suspect = any(v * self.world > max(1.0, math.ceil(b)) for v, b in zip(st["max_pass_visits"], st["budget"]))
+        flag = self.torch.tensor([1.0 if conflicts else 0.0, 1.0 if suspect else 0.0], dtype=self.torch.float64,
+                                 device=self.device)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
-        if float(flag.item()) == 0.0:
+        flags = flag.tolist()
+        if flags[1] != 0.0:
+            tot = self.torch.tensor([float(v) for v in st["max_pass_visits"]], dtype=self.torch.float64,
+                                    device=self.device)
+            self.dist.all_reduce(tot, op=self.dist.ReduceOp.SUM)
+            bud = self.torch.tensor([float(b) for b in st["budget"]], dtype=self.torch.float64, device=self.device)
+            self.dist.all_reduce(bud, op=self.dist.ReduceOp.MAX)
+            for which, (v, b) in enumerate(zip(tot.tolist(), bud.tolist())):
+                if v > max(1.0, math.ceil(b)):
+                    self.local.step_end(False)
+                    raise EggError("collision budget may bind across ranks (type %d: up to %d visits in a pass, "
+                                   "budget %.2f): exact-budget mode needs all particles of the type on one rank"
+                                   % (which, int(v), b))
+        if flags[0] == 0.0:
             self.local.step_end(True)
             return 0
         self.local.step_end(False)

@@ -183,6 +183,8 @@ typedef struct {
     double kernel_ms[2];     /* device time of that type's step launches in the most recent _step (EGG_OPT_TIMING) */
     double kernel_ms_sum[2]; /* the same, summed over all committed steps since EGG_OPT_TIMING was switched on */
     int64_t timed_steps;
+    int64_t max_pass_visits[2]; /* most pairs visited in one collision pass of the most recent _step, per type */
+    double budget[2];           /* max_collision_fraction * N^2 of the most recent _step (L:1752-1753), per type */
 } egg_stats;
 int egg_get_stats(egg_handle *h, egg_stats *out);
 

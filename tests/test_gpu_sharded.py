@@ -66,17 +66,44 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_with_hand_over_match_single_handler(oracle_mod):
+def _budget_worker(rank, world, port, q):
+    """one batch per rank: 30 yolk particles globally, budget 0.05 * 30^2 = 45 visits per pass, which the
+    two blobs together exceed -> the reference's early return would fire -> must be refused, not stepped"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from egg_fluid_simulation_amd import EggError, SimulationHandler
+    from egg_fluid_simulation_amd.sharding import ShardedSimulationHandler, SlabLayout
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = ShardedSimulationHandler(SlabLayout([0.0, 1000.0, 2000.0]), rank, dist,
+                                      lambda: SimulationHandler(device=0), device="cpu")
+        sh.add(500.0, 500.0, 50, 15)
+        sh.add(1500.0, 500.0, 50, 15)
+        raised_at = None
+        for k in range(4):
+            try:
+                sh.step(1 / 60)
+            except EggError as e:
+                raised_at = (k, str(e))
+                break
+        q.put((rank, raised_at, sh.local.stats()["max_pass_visits"], sh.local.stats()["budget"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_two(worker):
+    import queue
+    import time
+
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
-    import queue
-    import time
     deadline = time.time() + 240
     while len(res) < 2 and time.time() < deadline:
         try:
@@ -90,6 +117,20 @@ def test_two_ranks_with_hand_over_match_single_handler(oracle_mod):
         if p.is_alive():
             p.kill()  # the exact child started above
     assert len(res) == 2 and all(p.exitcode == 0 for p in procs), "a rank failed: see its traceback above"
+    return res
+
+
+def test_binding_budget_across_ranks_is_refused():
+    res = _run_two(_budget_worker)
+    for r in (0, 1):
+        _, raised_at, visits, budget = res[r]
+        assert budget[1] == 45.0, budget  # every rank prices the budget on the GLOBAL particle count
+        assert raised_at is not None and raised_at[0] == 1, (raised_at, visits, budget)
+        assert "budget" in raised_at[1]
+
+
+def test_two_ranks_with_hand_over_match_single_handler(oracle_mod):
+    res = _run_two(_worker)
 
     centers, target = _scenario()
     o = oracle_mod.Oracle()

@@ -1044,7 +1044,93 @@ extern "C" __global__ void egg_microbench_kernel(int mode, int iters, int active
     double2 pa = lpos[lane], pb = lpos[lane + 64];
     const double2 wra = lwr[lane], wrb = lwr[lane + 64];
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (lane < active_lanes) {
+    if (mode >= 2) {
+        // raw issue/latency probes: 2/3/4 = 1/2/4 independent fma chains, 5 = rcp chain, 6 = rsq chain,
+        // 7 = compare + exec-mask branch per fma, 8 = LDS store -> load round trip
+        double x0 = pa.x, x1 = pa.y, x2 = pb.x, x3 = pb.y;
+        const double m = 1.0000001, c = 1e-9;
+        if (lane < active_lanes) {
+            for (int i = 0; i < iters; ++i) {
+                if (mode == 2) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) x0 = __builtin_fma(x0, m, c);
+                } else if (mode == 3) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        x0 = __builtin_fma(x0, m, c);
+                        x1 = __builtin_fma(x1, m, c);
+                    }
+                } else if (mode == 4) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        x0 = __builtin_fma(x0, m, c);
+                        x1 = __builtin_fma(x1, m, c);
+                        x2 = __builtin_fma(x2, m, c);
+                        x3 = __builtin_fma(x3, m, c);
+                    }
+                } else if (mode == 5) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) x0 = __builtin_amdgcn_rcp(x0);
+                } else if (mode == 6) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) x0 = __builtin_amdgcn_rsq(x0);
+                } else if (mode == 7) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        if (x0 > 1e300) x0 = x0 * 0.5;  // never taken; compare + saveexec + branch
+                        __asm__ volatile("" : "+v"(x0));
+                        x0 = __builtin_fma(x0, m, c);
+                    }
+                } else if (mode == 14) {  // calibration: 32 x s_nop 15 = 512 core cycles
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) __asm__ volatile("s_nop 15");
+                } else if (mode == 9) {
+                    float f = (float)x0;
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) f = __builtin_fmaf(f, 1.0000001f, 1e-9f);
+                    x0 = f;
+                } else if (mode == 10) {
+                    int q = (int)x0 + i;
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        q = q * 3 + 1;
+                        __asm__ volatile("" : "+v"(q));
+                    }
+                    x0 = q;
+                } else if (mode == 11) {
+                    int acc = 0;
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        acc += (x0 > (double)u) ? 1 : 0;  // v_cmp_f64 + v_addc / cndmask, no branch
+                        __asm__ volatile("" : "+v"(acc));
+                    }
+                    x0 += acc;
+                } else if (mode == 12) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        x0 = x0 + c;
+                        __asm__ volatile("" : "+v"(x0));
+                    }
+                } else if (mode == 13) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        x0 = x0 * m;
+                        __asm__ volatile("" : "+v"(x0));
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        lpos[lane].x = x0;
+                        __asm__ volatile("" ::: "memory");
+                        x0 = lpos[lane].x;
+                        __asm__ volatile("" : "+v"(x0));
+                    }
+                }
+            }
+        }
+        pa.x = x0 + x1;
+        pb.y = x2 + x3;
+    } else if (lane < active_lanes) {
         for (int i = 0; i < iters; ++i) {
             if (mode == 1) {
                 pa = lpos[lane];

@@ -10,3 +10,18 @@ for mode in (0, 1):
         L.egg_microbench(mode, 2000, lanes, C.byref(c))
         L.egg_microbench(mode, 2000, lanes, C.byref(c))
         print("mode=%d active_lanes=%d: %.1f cycles per projection" % (mode, lanes, c.value / 2000.0))
+names = {2: "1 fma chain", 3: "2 fma chains", 4: "4 fma chains", 5: "rcp chain", 6: "rsq chain",
+         7: "cmp+branch+fma", 8: "LDS store->load", 9: "f32 fma chain", 10: "i32 mad chain",
+         11: "f64 cmp + int add", 12: "f64 add chain", 13: "f64 mul chain", 14: "s_nop 15 (16 core cycles)"}
+import time
+for rep in range(2):
+    for mode in [14] + list(range(2, 14)) + [14]:
+        best = None
+        for k in range(4):
+            c = C.c_ulonglong()
+            t0 = time.perf_counter()
+            L.egg_microbench(mode, 20000, 64, C.byref(c))
+            dt = time.perf_counter() - t0
+            v = c.value / 20000.0 / 32
+            best = v if best is None else min(best, v)
+        print("mode=%2d (%s): %.2f ticks per instruction; last launch %.0f ticks/us wall" % (mode, names[mode], best, c.value / (dt * 1e6)))

@@ -180,18 +180,38 @@ __device__ __forceinline__ double egg_sqrt_core(double x) {  // valid for x in [
     g = __builtin_fma(d, h, g);
     return g;
 }
+// the same square root, plus a refined reciprocal of the root: the Goldschmidt iteration carries
+// h ~ 1 / (2 sqrt(x)) to ~2^-51, one Newton step on 2h gives the quality of egg_rcp_refined(root) without
+// the v_rcp_f64 and one of its two Newton steps (the quotient below only needs a faithful reciprocal)
+__device__ __forceinline__ void egg_sqrt_rcp_core(double x, double &root, double &rroot) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    root = g;
+    const double r0 = h + h;
+    const double e = __builtin_fma(-g, r0, 1.0);
+    rroot = __builtin_fma(r0, e, r0);
+}
 #define EGG_ARITH_LO 0x1p-300
 #define EGG_ARITH_HI 0x1p300
 
 // XPBD distance projection between two particles, L:1514-1545 with the collision caller
-// L:1632-1654 (and the numerically dead cohesion block L:1603-1630).  pa/pb are the current
-// positions, wra/wrb the (inverse mass, radius) records.  Returns true when pa/pb changed.
-__device__ inline bool project_pair(const Tile &t, int a, int b, double2 &pa, double2 &pb, double2 wra, double2 wrb,
-                                    double overlap, double compliance, double eps) {
+// L:1632-1654 (and the numerically dead cohesion block L:1603-1630), written operator by operator
+// like the reference.  pa/pb are the current positions, wra/wrb the (inverse mass, radius) records.
+// This is the general path; the pair scheduler calls it only for the rare pairs project_pair
+// below cannot prove to be inside the window of its hand-expanded arithmetic.
+__device__ __forceinline__ void project_pair_reference(const Tile &t, int a, int b, double2 &pa, double2 &pb, double2 wra,
+                                                    double2 wrb, double overlap, double compliance, double eps) {
     const double wa = wra.x, wb = wrb.x;
     const double wsum = wa + wb;
-    if (wsum < eps) return false;  // L:1601
-    bool changed = false;
+    if (wsum < eps) return;  // L:1601
     const double dx = pb.x - pa.x, dy = pb.y - pa.y;
     const double d2 = dx * dx + dy * dy;
     if (d2 <= 0.0) {
@@ -201,76 +221,97 @@ __device__ inline bool project_pair(const Tile &t, int a, int b, double2 &pa, do
             // observable effect is x_self + 0.0 (turns -0.0 into +0.0)
             pa.x = pa.x + 0.0;
             pa.y = pa.y + 0.0;
-            changed = true;
         }
     }
     const double min_distance = overlap * (wra.y + wrb.y);
-    const double md2 = min_distance * min_distance;
-    if (d2 <= md2) {
+    if (d2 <= min_distance * min_distance) {
         const double divisor = wsum + compliance;
-        // Fast path window.  d2 in [2^-600, 2^600] makes the scaling-free square root exact-equal to
-        // sqrt(); current >= eps (tested anyway for normalize, eps >= 2^-300 is checked by the host)
-        // and current <= 2^300 (from d2) cover the denominator of the normalisation; divisor >= eps is
-        // tested anyway; numerators must be non-zero normal numbers (a zero numerator would lose its
-        // sign in the hand expansion).  NaN fails every comparison.  Bitwise &: one branch.
-        const bool window = ((int)(d2 >= 0x1p-600) & (int)(d2 <= 0x1p600) & (int)(fabs(dx) >= EGG_ARITH_LO) &
-                             (int)(fabs(dy) >= EGG_ARITH_LO) & (int)(divisor <= EGG_ARITH_HI)) != 0;
-        double nx, ny, correction, violation;
-        bool fast = false;
-        if (__builtin_expect(window, 1)) {
-            const double current = egg_sqrt_core(d2);
-            violation = current - min_distance;
-            fast = ((int)(current >= eps) & (int)(divisor >= eps) & (int)(fabs(violation) >= EGG_ARITH_LO)) != 0;
-            if (__builtin_expect(fast, 1)) {
-                const double r_current = egg_rcp_refined(current);
-                const double r_divisor = egg_rcp_refined(divisor);
-                nx = egg_div_with_rcp(dx, current, r_current);
-                ny = egg_div_with_rcp(dy, current, r_current);
-                correction = egg_div_with_rcp(-violation, divisor, r_divisor);
-                // clamp(correction, -|violation|, |violation|): no NaN or signed-zero subtleties here
-                // (|violation| > 0), so min/max are the reference's two comparisons
-                const double max_correction = fabs(violation);
-                correction = fmin(fmax(correction, -max_correction), max_correction);
-            }
+        const double current = sqrt(d2);
+        const double violation = current - min_distance;
+        double nx, ny;
+        if (current < eps) {  // math.normalize, math.lua:53-60
+            nx = 0.0;
+            ny = 0.0;
+        } else {
+            nx = dx / current;
+            ny = dy / current;
         }
         double cax, cay, cbx, cby;
-        if (!fast) {  // the reference's expressions, operator by operator
-            const double current = sqrt(d2);
-            violation = current - min_distance;
-            if (current < eps) {  // math.normalize, math.lua:53-60
-                nx = 0.0;
-                ny = 0.0;
-            } else {
-                nx = dx / current;
-                ny = dy / current;
-            }
-            if (divisor < eps) {
-                cax = cay = cbx = cby = 0.0;
-            } else {
-                correction = -violation / divisor;
-                const double max_correction = fabs(violation);
-                if (correction < -max_correction) correction = -max_correction;
-                if (correction > max_correction) correction = max_correction;
-                cax = -nx * correction * wa;
-                cay = -ny * correction * wa;
-                cbx = nx * correction * wb;
-                cby = ny * correction * wb;
-            }
+        if (divisor < eps) {
+            cax = cay = cbx = cby = 0.0;
         } else {
-            // -nx * correction == -(nx * correction) bit for bit (rounding is sign-symmetric)
-            const double tx = nx * correction, ty = ny * correction;
-            cax = -tx * wa;
-            cay = -ty * wa;
-            cbx = tx * wb;
-            cby = ty * wb;
+            double correction = -violation / divisor;
+            const double max_correction = fabs(violation);
+            if (correction < -max_correction) correction = -max_correction;
+            if (correction > max_correction) correction = max_correction;
+            cax = -nx * correction * wa;
+            cay = -ny * correction * wa;
+            cbx = nx * correction * wb;
+            cby = ny * correction * wb;
         }
         pa.x = pa.x + cax;
         pa.y = pa.y + cay;
         pb.x = pb.x + cbx;
         pb.y = pb.y + cby;
-        changed = true;
     }
-    return changed;
+}
+
+// is the pair's position-independent data outside what the fast path below may assume?  Evaluated
+// once per pair when the visit lists are ranked (all lanes busy there) and kept as a flag bit in
+// the list entry, so the serial pair scheduler does not pay for these comparisons.  NaN fails every
+// comparison and therefore sets the flag.
+__device__ __forceinline__ bool pair_needs_reference(double2 wra, double2 wrb, double overlap, double compliance,
+                                                     double eps) {
+    const double wsum = wra.x + wrb.x;
+    const double divisor = wsum + compliance;
+    const double min_distance = overlap * (wra.y + wrb.y);
+    const double md2 = min_distance * min_distance;
+    const bool fine = ((int)(wsum >= eps) & (int)(divisor >= eps) & (int)(divisor <= EGG_ARITH_HI) &
+                       (int)(md2 <= 0x1p600)) != 0;
+    return !fine;
+}
+
+// The same projection for the pair scheduler: one branch for "within range", one for "inside the
+// arithmetic window", the rest straight-line.  `slow` is pair_needs_reference() of the pair.
+// Window argument: !slow gives wsum >= eps, eps <= divisor <= 2^300 and md2 <= 2^600, hence
+// d2 <= md2 <= 2^600; current >= eps (eps >= 2^-300 is enforced by the host) gives d2 >= 2^-601 up
+// to rounding, far inside the square root's window [2^-767, ...), and covers the normalisation's
+// denominator; numerators must be non-zero normal numbers (a zero numerator would lose its sign in the
+// hand expansion).  Anything else -- including NaN, which fails every comparison -- takes the
+// reference path from the unchanged inputs.
+__device__ __forceinline__ void project_pair(const Tile &t, int a, int b, bool slow, double2 &pa, double2 &pb,
+                                             double2 wra, double2 wrb, double overlap, double compliance, double eps) {
+    const double dx = pb.x - pa.x, dy = pb.y - pa.y;
+    const double d2 = dx * dx + dy * dy;
+    const double min_distance = overlap * (wra.y + wrb.y);
+    const double md2 = min_distance * min_distance;
+    if (((int)(d2 <= md2) | (int)slow) != 0) {
+        double current, r_current;
+        egg_sqrt_rcp_core(d2, current, r_current);
+        const double violation = current - min_distance;
+        const bool fast = ((int)!slow & (int)(current >= eps) & (int)(fabs(dx) >= EGG_ARITH_LO) &
+                           (int)(fabs(dy) >= EGG_ARITH_LO) & (int)(fabs(violation) >= EGG_ARITH_LO)) != 0;
+        if (__builtin_expect(fast, 1)) {
+            const double wa = wra.x, wb = wrb.x;
+            const double divisor = (wa + wb) + compliance;
+            const double r_divisor = egg_rcp_refined(divisor);
+            const double nx = egg_div_with_rcp(dx, current, r_current);
+            const double ny = egg_div_with_rcp(dy, current, r_current);
+            double correction = egg_div_with_rcp(-violation, divisor, r_divisor);
+            // clamp(correction, -|violation|, |violation|): no NaN or signed-zero subtleties here
+            // (|violation| > 0), so max/min are the reference's two comparisons
+            __asm__("v_max_f64 %0, %1, -|%2|" : "=v"(correction) : "v"(correction), "v"(violation));
+            __asm__("v_min_f64 %0, %1, |%2|" : "=v"(correction) : "v"(correction), "v"(violation));
+            // -nx * correction == -(nx * correction) bit for bit (rounding is sign-symmetric)
+            const double tx = nx * correction, ty = ny * correction;
+            pa.x = pa.x + -tx * wa;
+            pa.y = pa.y + -ty * wa;
+            pb.x = pb.x + tx * wb;
+            pb.y = pb.y + ty * wb;
+        } else {
+            project_pair_reference(t, a, b, pa, pb, wra, wrb, overlap, compliance, eps);
+        }
+    }
 }
 
 struct PassCtx {
@@ -443,7 +484,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
         uint32_t ent = t.own_pack[min(o0, t.lcap - 1)];
         while (__any(k < no)) {
             const bool live = k < no;
-            const int b = live ? (int)(ent & 0xFFFFu) : 0;
+            const int b = live ? (int)(ent & EGG_IDX) : 0;
             const uint32_t rb = ent >> 16;
             // relaxed workgroup-scope atomics keep these plain ds_read_b32 / ds_write_b32 (a volatile
             // access would go through the flat path); ordering is by issue order, see above
@@ -461,10 +502,9 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
             __asm__ volatile("" ::"v"(pa.x), "v"(pa.y), "v"(pb.x), "v"(pb.y), "v"(wrb.x), "v"(wrb.y), "v"(ent_next));
             const bool ready = live && da == nl + (uint32_t)k && db == rb;
             if (ready) {
-                if (project_pair(t, a, b, pa, pb, wra, wrb, overlap, compliance, eps)) {
-                    t.pos[a] = pa;
-                    t.pos[b] = pb;
-                }
+                project_pair(t, a, b, (ent & 0x8000u) != 0, pa, pb, wra, wrb, overlap, compliance, eps);
+                t.pos[a] = pa;
+                t.pos[b] = pb;
                 EGG_COMPILER_BARRIER();  // data first, then the counters that publish it
                 if (GLOBAL_STATE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __hip_atomic_store(&done[a], da + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -898,6 +938,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             for (int i = tid; i < n; i += nthreads) {
                 const int st = (int)t.inc_off[i], cn = (int)t.inc_off[i + 1] - st;
                 const uint32_t nown = t.own_off(cur)[i + 1] - t.own_off(cur)[i];
+                const double2 wri = t.wr[i];
                 uint32_t nl = 0;
                 for (int e = 0; e < cn; ++e) {
                     const uint32_t rec = t.inc_tmp[st + e];
@@ -907,7 +948,10 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                     // pairs visited by a larger self come after i's own visits (stale pass only)
                     if (cself > (uint32_t)i) rank += nown;
                     else ++nl;
-                    t.own_pack[rec >> 16] = (uint32_t)i | (rank << 16);
+                    // bit 15: this pair must take the reference path (position-independent part of the test)
+                    const uint32_t slow = pair_needs_reference(t.wr[cself], wri, A.overlap_factor, A.collision_compliance, eps)
+                                              ? 0x8000u : 0u;
+                    t.own_pack[rec >> 16] = (uint32_t)i | slow | (rank << 16);
                 }
                 t.nlo[i] = (uint16_t)nl;
             }
@@ -1136,7 +1180,7 @@ extern "C" __global__ void egg_microbench_kernel(int mode, int iters, int active
                 pa = lpos[lane];
                 pb = lpos[lane + 64];
             }
-            project_pair(t, lane, lane + 64, pa, pb, wra, wrb, 2.0, 36.0, 1e-8);
+            project_pair(t, lane, lane + 64, (iters & 0x40000000) != 0, pa, pb, wra, wrb, 2.0, 36.0, 1e-8);
             if (mode == 1) {
                 lpos[lane] = pa;
                 lpos[lane + 64] = pb;
@@ -1198,8 +1242,13 @@ extern "C" __global__ void egg_selftest_arith_kernel(unsigned long long seed, in
         // square root: |n| spans [2^-300, 2^300]; its square (up to rounding) spans the sqrt window
         double x = (k & 1) ? fabs(n) : n * n;
         if (x >= 0x1p-600 && x <= 0x1p600) {
-            double ws = sqrt(x), gs = egg_sqrt_core(x);
+            double ws = sqrt(x), gs = egg_sqrt_core(x), gr, rr;
             if (__double_as_longlong(ws) != __double_as_longlong(gs)) ++bad;
+            // the projection's normalisation: numerator / sqrt(x) through the reciprocal the root core yields
+            egg_sqrt_rcp_core(x, gr, rr);
+            if (__double_as_longlong(ws) != __double_as_longlong(gr)) ++bad;
+            double wq = d / ws, gq = egg_div_with_rcp(d, gr, rr);
+            if (__double_as_longlong(wq) != __double_as_longlong(gq)) ++bad;
         }
     }
     if (bad) atomicAdd(mismatches, bad);

@@ -783,7 +783,8 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.use_grid = lc.use_grid;
         A.lcap = lc.lcap;
         // more tiles than the chip can hold at one per CU: idle waves yield their issue slots
-        A.spin_sleep = (h->opt_spin_sleep < 0) ? (lc.n_tiles > 2 * h->prop.multiProcessorCount ? 1 : 0) : h->opt_spin_sleep;
+        A.spin_sleep = (h->opt_spin_sleep < 0) ? ((lc.n_tiles > 2 * h->prop.multiProcessorCount || lc.global_state) ? 1 : 0)
+                                               : h->opt_spin_sleep;
         A.status = s.d_status;
         A.scratch = s.d_scratch.p + lc.scratch_offset;
         A.scratch_stride = lc.scratch_stride;
@@ -947,7 +948,9 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                 redo = true;
                 continue;
             }
-            if (st.fail_stall) return fail(h, EGG_ERR_INTERNAL, "pair scheduler stalled (type %d)", w);
+            if (st.fail_stall)
+                return fail(h, EGG_ERR_INTERNAL, "pair scheduler stalled (type %d, %s)", w,
+                            st.fail_stall == 2 ? "time limit reached" : "a particle's pair sequence did not finish");
             const bool single = s.single_tile || h->opt_force_single;
             if (!single) {
                 // budget check (L:1657-1658): the return can only fire if some pass visits more than

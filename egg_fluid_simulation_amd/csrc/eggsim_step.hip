@@ -454,11 +454,24 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_
 // of the workgroup run ahead of each other freely.
 #define EGG_COMPILER_BARRIER() __asm__ volatile("" ::: "memory")
 
+// Addresses of the tile state the scheduler touches: 32-bit LDS pointers (so that they can be kept in
+// one VGPR each across the spin loop), generic pointers when the state lives in global memory.
+typedef double egg_d2 __attribute__((ext_vector_type(2)));  // double2 without member functions
+template <bool GLOBAL_STATE, class T>
+struct StatePtr {
+    using type = __attribute__((address_space(3))) T *;
+};
+template <class T>
+struct StatePtr<true, T> {
+    using type = T *;
+};
+
 template <bool GLOBAL_STATE>
 __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, int nthreads, double overlap,
                                        double compliance, double eps, int total, int spin_sleep,
                                        unsigned int &spins_out) {
-    uint32_t *done = t.done;
+    using P32 = typename StatePtr<GLOBAL_STATE, uint32_t>::type;
+    using PD2 = typename StatePtr<GLOBAL_STATE, egg_d2>::type;
     int solved = 0;
     unsigned int spins = 0;
     // A thread walks its particles in ascending order (one particle when n <= nthreads).  That
@@ -471,8 +484,15 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
     const int spread = (nthreads >= 4 * n) ? 4 : (nthreads >= 2 * n) ? 2 : 1;
     const int slots = nthreads / spread;
     const int per = (n + slots - 1) / slots;
-    const unsigned int cap = 16u * (unsigned int)(total + 8) + 4096u;
-    for (int base = 0; base < per; ++base) {
+    // Hang guard (cannot trigger with consistent lists): wall-clock based, because the number of turns a
+    // waiting wave takes says nothing about progress -- it depends on how fast a turn is relative to a
+    // projection (sixteen spinning waves against global memory outran a turn-count limit).  s_memrealtime
+    // ticks at 100 MHz; it is read every 1024th turn on the scalar unit.
+    const unsigned long long t_start = wall_clock64();
+    const unsigned long long t_limit = 1000000000ull;  // 10 s for one pass of one tile
+    (void)total;
+    bool timed_out = false;
+    for (int base = 0; base < per && !timed_out; ++base) {
         const int a = (tid % spread == 0) ? tid / spread + base * slots : n;
         const bool has = a < n;
         const int as = has ? a : 0;
@@ -480,46 +500,88 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
         const int no = has ? (int)t.own_off(cur)[a + 1] - o0 : 0;
         const uint32_t nl = t.nlo[as];
         const double2 wra = t.wr[as];
+        const P32 p_da = (P32)&t.done[as];
+        const PD2 p_pa = (PD2)&t.pos[as];
         int k = 0;
         uint32_t ent = t.own_pack[min(o0, t.lcap - 1)];
-        while (__any(k < no)) {
+        // Everything that depends only on WHICH pair is next is computed when the thread moves on to that
+        // pair, not in every turn of the spin loop: a turn is six LDS loads and two compares.  A thread
+        // without a pending pair waits for a counter value that never comes.
+        uint32_t want_a, want_b;
+        P32 p_db;
+        PD2 p_pb, p_wb;
+        int i_next;
+        auto aim = [&]() {
             const bool live = k < no;
             const int b = live ? (int)(ent & EGG_IDX) : 0;
-            const uint32_t rb = ent >> 16;
+            want_a = live ? nl + (uint32_t)k : 0xFFFFFFFFu;
+            want_b = ent >> 16;
+            p_db = (P32)&t.done[b];
+            p_pb = (PD2)&t.pos[b];
+            p_wb = (PD2)&t.wr[b];
+            i_next = min(o0 + k + 1, t.lcap - 1);
+            if (!GLOBAL_STATE)  // keep them in registers; do not re-derive them from `ent` in the loop
+                __asm__ volatile("" : "+v"(want_a), "+v"(want_b), "+v"(p_db), "+v"(p_pb), "+v"(p_wb), "+v"(i_next));
+        };
+        aim();
+        while (__any(k < no)) {
             // relaxed workgroup-scope atomics keep these plain ds_read_b32 / ds_write_b32 (a volatile
             // access would go through the flat path); ordering is by issue order, see above
-            const uint32_t da = __hip_atomic_load(&done[as], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t db = __hip_atomic_load(&done[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t da = __hip_atomic_load(p_da, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t db = __hip_atomic_load(p_db, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             EGG_COMPILER_BARRIER();  // counters first, then the data they guard
-            // global memory: no issue-order guarantee between waves -> a real acquire after the counters
-            if (GLOBAL_STATE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            double2 pa = t.pos[as];
-            double2 pb = t.pos[b];
-            const double2 wrb = t.wr[b];
-            const uint32_t ent_next = t.own_pack[min(o0 + k + 1, t.lcap - 1)];
+            // global memory: the counter loads go to L2 while a position load may hit in L1 and be performed
+            // first -> the counters must have RETURNED before the data they guard is requested (a
+            // workgroup-scope acquire fence alone emits no wait on this target)
+            if (GLOBAL_STATE) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifndef EGG_NO_GS_WAIT
+                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            }
+            const egg_d2 va = *p_pa, vb = *p_pb, vw = *p_wb;
+            double2 pa = make_double2(va.x, va.y);
+            double2 pb = make_double2(vb.x, vb.y);
+            const double2 wrb = make_double2(vw.x, vw.y);
+            const uint32_t ent_next = t.own_pack[i_next];
             // consume the speculative loads here so that they are issued back to back with the
             // counters instead of being sunk behind the readiness branch (one LDS latency, not four)
             __asm__ volatile("" ::"v"(pa.x), "v"(pa.y), "v"(pb.x), "v"(pb.y), "v"(wrb.x), "v"(wrb.y), "v"(ent_next));
-            const bool ready = live && da == nl + (uint32_t)k && db == rb;
+            const bool ready = ((int)(da == want_a) & (int)(db == want_b)) != 0;
             if (ready) {
-                project_pair(t, a, b, (ent & 0x8000u) != 0, pa, pb, wra, wrb, overlap, compliance, eps);
-                t.pos[a] = pa;
-                t.pos[b] = pb;
+                project_pair(t, a, (int)(ent & EGG_IDX), (ent & 0x8000u) != 0, pa, pb, wra, wrb, overlap, compliance, eps);
+                *p_pa = (egg_d2){pa.x, pa.y};
+                *p_pb = (egg_d2){pb.x, pb.y};
                 EGG_COMPILER_BARRIER();  // data first, then the counters that publish it
-                if (GLOBAL_STATE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __hip_atomic_store(&done[a], da + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&done[b], db + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (GLOBAL_STATE) {  // positions acknowledged by memory before the counters announce them
+#ifndef EGG_NO_GS_WAIT
+                    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                }
+                __hip_atomic_store(p_da, da + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(p_db, db + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ++k;
                 ent = ent_next;
                 ++solved;
+                aim();
             }
             // a wave with nothing ready only burns issue slots its SIMD neighbours could use; park it
             // briefly when several tiles share the CU (costs ~3 % when a tile has the CU to itself)
-            if (spin_sleep && !__any(ready)) __builtin_amdgcn_s_sleep(2);
-            if (++spins > cap) break;  // cannot happen; guards against a hang
+            if (spin_sleep && !__any(ready)) {
+                if (GLOBAL_STATE)
+                    __builtin_amdgcn_s_sleep(16);  // keep the waiting waves out of the working wave's memory pipeline
+                else
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            ++spins;
+            if ((spins & 1023u) == 0u && wall_clock64() - t_start > t_limit) {
+                timed_out = true;
+                break;
+            }
         }
     }
-    spins_out = spins;
+    spins_out = timed_out ? 0xFFFFFFFFu : spins;
     return solved;
 }
 
@@ -973,7 +1035,8 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 }
                 (void)solved;
                 if (__syncthreads_or(short_)) {  // cannot happen with consistent lists
-                    if (tid == 0) atomicExch(&A.status->fail_stall, 1);
+                    const int timed_out = __syncthreads_or(spins == 0xFFFFFFFFu);
+                    if (tid == 0) atomicExch(&A.status->fail_stall, timed_out ? 2 : 1);
                     return;
                 }
             }

@@ -24,6 +24,7 @@
 extern "C" __global__ void egg_step_kernel(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_occ(EggStepArgs A);
+extern "C" __global__ void egg_step_kernel_wide(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gs(EggStepArgs A);
 extern "C" __global__ void egg_selftest_arith_kernel(unsigned long long, int, unsigned long long *);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
@@ -116,6 +117,8 @@ struct LaunchClass {  // tiles of similar size share a launch (uniform LDS geome
     int nmax = 0, amax = 0, ccap = 0, use_grid = 0, lcap = 0;
     int global_lists = 0;  // visit lists in the scratch buffer instead of LDS
     int global_state = 0;  // everything in the scratch buffer (islands too large for LDS)
+    int threads = 0;       // workgroup size
+    int wide = 0;          // three lanes per particle for the list-building phases (egg_step_kernel_wide)
     size_t scratch_stride = 0;
     size_t lds = 0, scratch_offset = 0;
 };
@@ -187,7 +190,7 @@ struct egg_handle {
     int opt_tile_target = 0;
     int opt_timing = 0;
     int opt_force_single = 0;
-    int opt_spread = 1;
+    int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
     int opt_spin_sleep = -1;  // -1 auto
     int opt_force_global_state = 0;  // test hook: run every tile through the global-memory-state kernel  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
     hipDeviceProp_t prop{};
@@ -638,7 +641,7 @@ int retile(egg_handle *h, int which) {
         lcap = std::min<size_t>(lcap, kMaxListEntries);
         lcap = (lcap + 7) & ~(size_t)7;
         lc.lcap = (int)lcap;
-        const int threads = egg_step_threads(lc.nmax, h->opt_spread);
+        int threads = egg_step_threads(lc.nmax, 1);
         lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0, threads);
         bool want_global_state = h->opt_force_global_state != 0;
         if (!want_global_state && (lc.lds > h->lds_limit || lc.lds > 64 * 1024 || threads > 256)) {
@@ -662,6 +665,20 @@ int retile(egg_handle *h, int which) {
         } else if (lc.global_lists) {
             lc.scratch_stride = (egg_step_scratch_bytes(lc.lcap, single ? 1 : 0) + 255) & ~(size_t)255;
         }
+        // A tile that has a CU (almost) to itself leaves most of the CU's issue slots idle: give it three
+        // lanes per particle, which the kernel uses to build the visit lists column-wise.  With more
+        // tiles than that, one lane per particle keeps the most tiles resident.
+        if (!lc.global_lists && !lc.global_state) {
+            int spread = h->opt_spread;
+            // (two such workgroups do not fit one CU's register file, so: at most one tile per CU)
+            if (spread <= 0) spread = (lc.n_tiles <= h->prop.multiProcessorCount) ? 3 : 1;
+            const int wide_threads = egg_step_threads(lc.nmax, spread);
+            if (spread > 1 && wide_threads <= 512 && wide_threads >= 3 * lc.nmax) {
+                threads = wide_threads;
+                lc.wide = 1;
+            }
+        }
+        lc.threads = threads;
         if (lc.global_lists) {
             scratch_bytes = (scratch_bytes + 255) & ~(size_t)255;
             lc.scratch_offset = scratch_bytes;
@@ -788,18 +805,17 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.status = s.d_status;
         A.scratch = s.d_scratch.p + lc.scratch_offset;
         A.scratch_stride = lc.scratch_stride;
+        const dim3 grid((unsigned)lc.n_tiles), block((unsigned)lc.threads);
         if (lc.global_state)
-            hipLaunchKernelGGL(egg_step_kernel_gs, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
-                               64, s.stream, A);
+            hipLaunchKernelGGL(egg_step_kernel_gs, grid, block, 64, s.stream, A);
         else if (lc.global_lists)
-            hipLaunchKernelGGL(egg_step_kernel_gl, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
-                               lc.lds, s.stream, A);
+            hipLaunchKernelGGL(egg_step_kernel_gl, grid, block, lc.lds, s.stream, A);
+        else if (lc.wide)
+            hipLaunchKernelGGL(egg_step_kernel_wide, grid, block, lc.lds, s.stream, A);
         else if (lc.n_tiles >= 4 * h->prop.multiProcessorCount)  // throughput regime: residency over spill-freedom
-            hipLaunchKernelGGL(egg_step_kernel_occ, dim3((unsigned)lc.n_tiles),
-                               dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)), lc.lds, s.stream, A);
+            hipLaunchKernelGGL(egg_step_kernel_occ, grid, block, lc.lds, s.stream, A);
         else
-            hipLaunchKernelGGL(egg_step_kernel, dim3((unsigned)lc.n_tiles), dim3((unsigned)egg_step_threads(lc.nmax, h->opt_spread)),
-                               lc.lds, s.stream, A);
+            hipLaunchKernelGGL(egg_step_kernel, grid, block, lc.lds, s.stream, A);
         HIP_TRY(h, hipGetLastError());
         h->stats.kernel_launches++;
     }
@@ -1111,6 +1127,8 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
             e = hipFuncSetAttribute((const void *)egg_step_kernel_gl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)egg_step_kernel_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess) {
             h->lds_limit = want;
             break;
@@ -1752,7 +1770,8 @@ int egg_set_option(egg_handle *h, int option, double value) {
             h->stats.timed_steps = 0;
             return EGG_OK;
         case EGG_OPT_THREADS_PER_PARTICLE:
-            if (value != 1 && value != 2 && value != 4) return fail(h, EGG_ERR_INVALID_ARGUMENT, "threads per particle must be 1, 2 or 4");
+            if (!(value >= 0 && value <= 4) || value != (int)value)
+                return fail(h, EGG_ERR_INVALID_ARGUMENT, "threads per particle must be 0 (automatic), 1, 2, 3 or 4");
             h->opt_spread = (int)value;
             return EGG_OK;
         case EGG_OPT_FORCE_GLOBAL_STATE:

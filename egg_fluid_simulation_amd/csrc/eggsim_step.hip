@@ -105,19 +105,29 @@ __device__ inline int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-// exclusive prefix sum of cnt[0..n) into off[0..n], off[n] = total.  Executed by wave 0 of the
-// workgroup only (the arrays are a few hundred entries); callers put barriers around it.
-__device__ inline void wave0_exclusive_scan(const uint32_t *cnt, uint32_t *off, int n, int tid) {
-    if (tid >= 64) return;
-    int carry = 0;
-    for (int base = 0; base < n; base += 64) {
-        int i = base + tid;
-        int v = (i < n) ? (int)cnt[i] : 0;
-        int incl = wave_incl_scan(v, tid);
-        if (i < n) off[i] = (uint32_t)(carry + incl - v);
-        carry += __shfl(incl, 63, 64);
+// exclusive prefix sum of cnt[0..len) into off[0..len], off[len] = total, by the whole workgroup: every thread takes a run of consecutive entries, one
+// wave scan, one barrier for the per-wave totals.  PACK writes the cell records (start << 16 | count)
+// and no total.  cnt and off may be the same array.  The caller puts barriers before (cnt complete) and
+// after (off visible); wtot holds one word per wave.
+template <bool PACK>
+__device__ inline void block_exclusive_scan(const uint32_t *cnt, uint32_t *off, int len, int tid, int nthreads,
+                                            uint32_t *wtot) {
+    const int per = (len + nthreads - 1) / nthreads;
+    const int b0 = tid * per, b1 = min(b0 + per, len);
+    uint32_t sum = 0;
+    for (int q = b0; q < b1; ++q) sum += cnt[q];
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t incl = (uint32_t)wave_incl_scan((int)sum, lane);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+    for (int q = b0; q < b1; ++q) {
+        const uint32_t v = cnt[q];
+        off[q] = PACK ? ((run << 16) | v) : run;
+        run += v;
     }
-    if (tid == 0) off[n] = (uint32_t)carry;
+    if (!PACK && tid == nthreads - 1) off[len] = run;
 }
 
 __device__ inline int cell_slot(uint32_t ka, uint32_t kb) {
@@ -350,7 +360,7 @@ __device__ inline int enum_fresh(const Tile &t, int cur, int i, uint32_t *dst) {
         for (int q = 0; q < 4; ++q)
             if (q < cn && (int)it[s][q] > i) {
                 if (FILL) {
-                    dst[count] = it[s][q];
+                    dst[count] = (uint32_t)it[s][q] | ((uint32_t)i << 16);
                     atomicAdd(&t.done[it[s][q]], 1u);
                 }
                 ++count;
@@ -359,7 +369,34 @@ __device__ inline int enum_fresh(const Tile &t, int cur, int i, uint32_t *dst) {
             int j = items[st + e];
             if (j > i) {
                 if (FILL) {
-                    dst[count] = (uint32_t)j;
+                    dst[count] = (uint32_t)j | ((uint32_t)i << 16);
+                    atomicAdd(&t.done[j], 1u);
+                }
+                ++count;
+            }
+        }
+    }
+    return count;
+}
+
+// one column (x offset p - 1) of the same loop: the visit list of i is the concatenation of its three
+// columns, so three lanes can build it side by side when the workgroup has lanes to spare
+template <bool FILL>
+__device__ inline int enum_fresh_column(const Tile &t, int cur, int i, int p, uint32_t *dst) {
+    const uint32_t ki = t.ckey(cur)[i];
+    const uint16_t *items = t.hitems(cur);
+    uint32_t m[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) m[r] = cell_meta(t, cur, (uint32_t)((int)ki + (p - 1) * 65536 + (r - 1)));
+    int count = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int st = (int)(m[r] >> 16), cn = (int)(m[r] & 0xFFFFu);
+        for (int e = 0; e < cn; ++e) {
+            const int j = items[st + e];
+            if (j > i) {
+                if (FILL) {
+                    dst[count] = (uint32_t)j | ((uint32_t)i << 16);
                     atomicAdd(&t.done[j], 1u);
                 }
                 ++count;
@@ -402,11 +439,11 @@ __device__ inline bool accept_stale(const Tile &t, const PassCtx &c, int i, int 
 }
 
 template <bool FILL>
-__device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_t *dst) {
+__device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_t *dst, int s0 = 0, int s1 = 9) {
     const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.cur ^ 1);
     const uint32_t kni = kn[i], koi = ko[i];
     int count = 0;
-    for (int s = 0; s < 9; ++s) {
+    for (int s = s0; s < s1; ++s) {
         const uint32_t nk = (uint32_t)((int)kni + (s / 3 - 1) * 65536 + (s % 3 - 1));
         const uint32_t mo = cell_meta(t, c.cur ^ 1, nk), mn = cell_meta(t, c.cur, nk);
 #pragma unroll
@@ -428,7 +465,7 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_
                 for (int q = 0; q < 4; ++q)
                     if (e0 + q < cn && accept_stale(t, c, i, j[q], s, isnew, kni, koi, knj[q], koj[q])) {
                         if (FILL) {
-                            dst[count] = (uint32_t)j[q];
+                            dst[count] = (uint32_t)j[q] | ((uint32_t)i << 16);
                             atomicAdd(&t.done[j[q]], 1u);
                         }
                         ++count;
@@ -479,21 +516,18 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
     // a topological order of the dependencies, so a pair only ever waits for pairs of selves <= its
     // own self, and those belong to the same or an earlier slice [base * nthreads, ...) which
     // every thread finishes first.
-    // Particles can be spread over more threads (thread = particle * spread, EGG_OPT_THREADS_PER_PARTICLE);
-    // measured: no gain in latency, a loss in throughput, so the default is 1.
-    const int spread = (nthreads >= 4 * n) ? 4 : (nthreads >= 2 * n) ? 2 : 1;
-    const int slots = nthreads / spread;
-    const int per = (n + slots - 1) / slots;
+    // Threads beyond the particle count (wide workgroups) have nothing to schedule and wait at the barrier.
+    const int per = (n + nthreads - 1) / nthreads;
     // Hang guard (cannot trigger with consistent lists): wall-clock based, because the number of turns a
     // waiting wave takes says nothing about progress -- it depends on how fast a turn is relative to a
     // projection (sixteen spinning waves against global memory outran a turn-count limit).  s_memrealtime
-    // ticks at 100 MHz; it is read every 1024th turn on the scalar unit.
+    // ticks at 100 MHz; it is read every 1024th turn, on the scalar unit.
     const unsigned long long t_start = wall_clock64();
     const unsigned long long t_limit = 1000000000ull;  // 10 s for one pass of one tile
     (void)total;
     bool timed_out = false;
     for (int base = 0; base < per && !timed_out; ++base) {
-        const int a = (tid % spread == 0) ? tid / spread + base * slots : n;
+        const int a = tid + base * nthreads;
         const bool has = a < n;
         const int as = has ? a : 0;
         const int o0 = has ? (int)t.own_off(cur)[a] : 0;
@@ -523,8 +557,9 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
             if (!GLOBAL_STATE)  // keep them in registers; do not re-derive them from `ent` in the loop
                 __asm__ volatile("" : "+v"(want_a), "+v"(want_b), "+v"(p_db), "+v"(p_pb), "+v"(p_wb), "+v"(i_next));
         };
+        int no_live = no;  // == no unless the hang guard fires
         aim();
-        while (__any(k < no)) {
+        [[clang::code_align(64)]] while (__any(k < no_live)) {
             // relaxed workgroup-scope atomics keep these plain ds_read_b32 / ds_write_b32 (a volatile
             // access would go through the flat path); ordering is by issue order, see above
             const uint32_t da = __hip_atomic_load(p_da, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -568,16 +603,18 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
             }
             // a wave with nothing ready only burns issue slots its SIMD neighbours could use; park it
             // briefly when several tiles share the CU (costs ~3 % when a tile has the CU to itself)
-            if (spin_sleep && !__any(ready)) {
+            if (__builtin_expect(spin_sleep != 0, 0) && !__any(ready)) {
                 if (GLOBAL_STATE)
                     __builtin_amdgcn_s_sleep(16);  // keep the waiting waves out of the working wave's memory pipeline
                 else
                     __builtin_amdgcn_s_sleep(2);
             }
             ++spins;
-            if ((spins & 1023u) == 0u && wall_clock64() - t_start > t_limit) {
-                timed_out = true;
-                break;
+            if (__builtin_expect((spins & 1023u) == 0u, 0)) {
+                if (wall_clock64() - t_start > t_limit) {  // give up: no lane has a pending pair any more
+                    timed_out = true;
+                    no_live = 0;
+                }
             }
         }
     }
@@ -752,6 +789,11 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     long long budget_m = (long long)ceil(A.budget);
     if (budget_m < 1) budget_m = 1;
 
+    // a workgroup with at least three lanes per particle builds the visit lists column-wise (launch
+    // classes that have a CU almost to themselves get such workgroups, see the host's launch_type)
+    const int parts = (nthreads >= 3 * n) ? 3 : 1;
+    __shared__ uint32_t wtot[16];  // per-wave totals of the workgroup-wide prefix sums
+
     int cur = 0;
     int have_prev = 0;  // buffers cur^1 hold an un-cleared previous pass
     int prev_uncut = 1;
@@ -854,16 +896,8 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 if (tid == 0) atomicExch(&A.status->fail_claim, 1);
                 return;
             }
-            if (tid < 64) {  // cell start offsets: exclusive scan of the per-cell counts (wave 0)
-                int carry = 0;
-                for (int base = 0; base < t.ncell; base += 64) {
-                    int h = base + lane;
-                    int v = (h < t.ncell) ? (int)t.cell(cur)[h] : 0;
-                    int incl = wave_incl_scan(v, lane);
-                    if (h < t.ncell) t.cell(cur)[h] = ((uint32_t)(carry + incl - v) << 16) | (uint32_t)v;
-                    carry += __shfl(incl, 63, 64);
-                }
-            }
+            // cell start offsets: exclusive scan of the per-cell counts, in place (start << 16 | count)
+            block_exclusive_scan<true>(t.cell(cur), t.cell(cur), t.ncell, tid, nthreads, wtot);
             __syncthreads();
             // unordered scatter, then rank inside the cell so that each cell's items ascend (L:1509)
             for (int i = tid; i < n; i += nthreads) {
@@ -883,14 +917,29 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             PROF(2)  // cell hash
 
             // ---------------------------------------- visit lists (count, scan, fill)
-            if (ctx.stale) {
+            // parts == 3: three lanes per particle, one per cell column; the per-column counts are scanned
+            // in `sub` (the transposition's scratch, unused until the lists are complete)
+            uint32_t *sub = t.inc_tmp;
+            if (parts == 3) {
+                for (int w = tid; w < 3 * n; w += nthreads) {
+                    const int i = w / 3, p = w - 3 * i;
+                    sub[w] = ctx.stale ? (uint32_t)enum_stale<false>(t, ctx, i, nullptr, 3 * p, 3 * p + 3)
+                                       : (uint32_t)enum_fresh_column<false>(t, cur, i, p, nullptr);
+                }
+            } else if (ctx.stale) {
                 for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_stale<false>(t, ctx, i, nullptr);
             } else {
                 for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_fresh<false>(t, cur, i, nullptr);
             }
             __syncthreads();
             PROF(3)  // visit count
-            wave0_exclusive_scan(t.fill, t.own_off(cur), n, tid);
+            if (parts == 3) {
+                block_exclusive_scan<false>(sub, sub, 3 * n, tid, nthreads, wtot);
+                __syncthreads();
+                for (int i = tid; i <= n; i += nthreads) t.own_off(cur)[i] = sub[3 * i];
+            } else {
+                block_exclusive_scan<false>(t.fill, t.own_off(cur), n, tid, nthreads, wtot);
+            }
             __syncthreads();
             int total = (int)t.own_off(cur)[n];
             max_list = max(max_list, (unsigned int)total);  // what this pass needs, even when it does not fit
@@ -902,6 +951,14 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                     atomicMax(&A.status->max_list, (unsigned long long)total);
                 }
                 return;
+            } else if (parts == 3) {
+                for (int w = tid; w < 3 * n; w += nthreads) {
+                    const int i = w / 3, p = w - 3 * i;
+                    if (ctx.stale)
+                        enum_stale<true>(t, ctx, i, &t.own_pack[sub[w]], 3 * p, 3 * p + 3);
+                    else
+                        enum_fresh_column<true>(t, cur, i, p, &t.own_pack[sub[w]]);
+                }
             } else if (ctx.stale) {
                 for (int i = tid; i < n; i += nthreads)
                     enum_stale<true>(t, ctx, i, &t.own_pack[t.own_off(cur)[i]]);
@@ -970,51 +1027,39 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             // ---- ranks: transpose the visit lists (incoming pairs per particle), rank every incoming
             //      pair inside its particle's sequence, and store the rank next to the visit entry
             // t.done holds the incoming-pair count of every particle (gathered by the fill pass)
-            wave0_exclusive_scan(t.done, t.inc_off, n, tid);
+            block_exclusive_scan<false>(t.done, t.inc_off, n, tid, nthreads, wtot);
             for (int i = tid; i < n; i += nthreads) t.fill[i] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += nthreads) {
-                t.done[i] = 0;  // from here on: the scheduler's progress counter
-                const uint32_t e0 = t.own_off(cur)[i], e1 = t.own_off(cur)[i + 1];
-                uint32_t e = e0;
-                for (; e + 4 <= e1; e += 4) {  // four independent chains in flight
-                    int j[4];
-                    uint32_t pos[4], base[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) j[q] = (int)(t.own_pack[e + q] & 0xFFFFu);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        pos[q] = atomicAdd(&t.fill[j[q]], 1u);
-                        base[q] = t.inc_off[j[q]];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) t.inc_tmp[base[q] + pos[q]] = (uint32_t)i | ((e + q) << 16);
-                }
-                for (; e < e1; ++e) {
-                    int j = (int)(t.own_pack[e] & 0xFFFFu);
-                    uint32_t pos = atomicAdd(&t.fill[j], 1u);
-                    t.inc_tmp[t.inc_off[j] + pos] = (uint32_t)i | (e << 16);
-                }
+            // one lane per visit entry (other | self << 16, as the fill pass left it): append it to the
+            // incoming list of `other`
+            for (int e = tid; e < total; e += nthreads) {
+                const uint32_t rec = t.own_pack[e];
+                const uint32_t j = rec & 0xFFFFu;
+                const uint32_t pos = atomicAdd(&t.fill[j], 1u);
+                t.inc_tmp[t.inc_off[j] + pos] = (rec >> 16) | ((uint32_t)e << 16);
             }
+            for (int i = tid; i < n; i += nthreads) t.done[i] = 0;  // from here on: the scheduler's progress counter
             __syncthreads();
+            // one lane per incoming entry: its rank in `other`'s pair sequence = incoming pairs from smaller
+            // selves, then other's own visits, then incoming pairs from larger selves (stale pass only)
+            for (int x = tid; x < total; x += nthreads) {
+                const uint32_t rec = t.inc_tmp[x];
+                const uint32_t cself = rec & 0xFFFFu, e = rec >> 16;
+                const int i = (int)(t.own_pack[e] & 0xFFFFu);  // the `other` of entry e: whose incoming list x is in
+                const int st = (int)t.inc_off[i], cn = (int)t.inc_off[i + 1] - st;
+                uint32_t rank = 0;
+                for (int f = 0; f < cn; ++f) rank += ((t.inc_tmp[st + f] & 0xFFFFu) < cself) ? 1u : 0u;
+                if (cself > (uint32_t)i) rank += t.own_off(cur)[i + 1] - t.own_off(cur)[i];
+                // bit 15: this pair must take the reference path (position-independent part of the test)
+                const uint32_t slow = pair_needs_reference(t.wr[cself], t.wr[i], A.overlap_factor, A.collision_compliance, eps)
+                                          ? 0x8000u : 0u;
+                t.own_pack[e] = (uint32_t)i | slow | (rank << 16);
+            }
+            // pairs in which a particle is `other` of a smaller self come before its own visits
             for (int i = tid; i < n; i += nthreads) {
                 const int st = (int)t.inc_off[i], cn = (int)t.inc_off[i + 1] - st;
-                const uint32_t nown = t.own_off(cur)[i + 1] - t.own_off(cur)[i];
-                const double2 wri = t.wr[i];
                 uint32_t nl = 0;
-                for (int e = 0; e < cn; ++e) {
-                    const uint32_t rec = t.inc_tmp[st + e];
-                    const uint32_t cself = rec & 0xFFFFu;
-                    uint32_t rank = 0;
-                    for (int f = 0; f < cn; ++f) rank += ((t.inc_tmp[st + f] & 0xFFFFu) < cself) ? 1u : 0u;
-                    // pairs visited by a larger self come after i's own visits (stale pass only)
-                    if (cself > (uint32_t)i) rank += nown;
-                    else ++nl;
-                    // bit 15: this pair must take the reference path (position-independent part of the test)
-                    const uint32_t slow = pair_needs_reference(t.wr[cself], wri, A.overlap_factor, A.collision_compliance, eps)
-                                              ? 0x8000u : 0u;
-                    t.own_pack[rec >> 16] = (uint32_t)i | slow | (rank << 16);
-                }
+                for (int f = 0; f < cn; ++f) nl += ((t.inc_tmp[st + f] & 0xFFFFu) < (uint32_t)i) ? 1u : 0u;
                 t.nlo[i] = (uint16_t)nl;
             }
             __syncthreads();
@@ -1125,6 +1170,9 @@ extern "C" __global__ void __launch_bounds__(256) egg_step_kernel(EggStepArgs A)
 // chip, six resident tiles per CU beat the spill-free build's four (measured: 2.75 -> 2.15 ms per
 // step at 4096 batches), while a tile that has its CU to itself is ~3 % slower
 extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_occ(EggStepArgs A) { egg_step_body<false, false>(A); }
+// up to 512 threads (256 registers per lane): tiles that have a CU to themselves run with three lanes per
+// particle, which build the visit lists column-wise; the pair scheduler still uses one lane per particle
+extern "C" __global__ void __launch_bounds__(512) egg_step_kernel_wide(EggStepArgs A) { egg_step_body<false, false>(A); }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true, false>(A); }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs(EggStepArgs A) { egg_step_body<true, true>(A); }
 
@@ -1139,7 +1187,7 @@ extern "C" __global__ void egg_microbench_kernel(int mode, int iters, int active
     Tile t;
     t.abatch = lbatch;
     t.aslot = lslot;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;  // several waves (mode >= 2 only) run the same probe side by side
     lpos[lane] = make_double2(10.0 + lane * 0.37, 5.0 + lane * 0.11);
     lpos[lane + 64] = make_double2(17.0 + lane * 0.35, 9.0 + lane * 0.13);
     lwr[lane] = make_double2(0.7 + 0.001 * lane, 4.0);
@@ -1253,7 +1301,7 @@ extern "C" __global__ void egg_microbench_kernel(int mode, int iters, int active
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         out[0] = t1 - t0;
         out[1] = (unsigned long long)__double_as_longlong(pa.x + pb.y);
     }
@@ -1261,7 +1309,9 @@ extern "C" __global__ void egg_microbench_kernel(int mode, int iters, int active
 extern "C" void egg_microbench(int mode, int iters, int active_lanes, unsigned long long *cycles) {
     unsigned long long *d = nullptr;
     (void)hipMalloc((void **)&d, 16);
-    hipLaunchKernelGGL(egg_microbench_kernel, dim3(1), dim3(64), 0, 0, mode, iters, active_lanes, d);
+    // mode >= 100: (mode % 100) run by mode / 100 waves of one workgroup
+    const int waves = mode >= 100 ? mode / 100 : 1;
+    hipLaunchKernelGGL(egg_microbench_kernel, dim3(1), dim3(64 * waves), 0, 0, mode % 100, iters, active_lanes, d);
     unsigned long long h[2] = {0, 0};
     (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
     (void)hipFree(d);

@@ -199,7 +199,7 @@ enum {
     EGG_OPT_TILE_TARGET_PARTICLES,  /* pack independent islands into tiles up to this size (0 = one island per tile) */
     EGG_OPT_TIMING,                 /* 1: record HIP events around the step kernels */
     EGG_OPT_FORCE_SINGLE_TILE,      /* 1: always run each type as one tile (exact budget path) */
-    EGG_OPT_THREADS_PER_PARTICLE,   /* 1, 2 or 4: spread a tile's particles over more waves (latency vs occupancy) */
+    EGG_OPT_THREADS_PER_PARTICLE,   /* lanes per particle: 0 automatic (3 for tiles that have a CU to themselves: visit lists built column-wise), 1 or 3 forced */
     EGG_OPT_SPIN_SLEEP,             /* -1 auto, 0 never, 1 always: idle dataflow waves sleep between polls */
     EGG_OPT_BUDGET_PARTICLES_WHITE, /* multi-GPU: N of the collision budget 0.05 N^2 (L:1752-1753) = particles of ALL ranks; -1 = local */
     EGG_OPT_BUDGET_PARTICLES_YOLK,

@@ -25,3 +25,12 @@ for rep in range(2):
             v = c.value / 20000.0 / 32
             best = v if best is None else min(best, v)
         print("mode=%2d (%s): %.2f ticks per instruction; last launch %.0f ticks/us wall" % (mode, names[mode], best, c.value / (dt * 1e6)))
+print("several waves of one workgroup running the f64 fma chain (mode 2) side by side:")
+for waves in (1, 2, 4, 8, 12, 16):
+    best = None
+    for k in range(3):
+        c = C.c_ulonglong()
+        L.egg_microbench(100 * waves + 2, 20000, 64, C.byref(c))
+        v = c.value / 20000.0 / 32
+        best = v if best is None else min(best, v)
+    print("  %2d waves: %.2f ticks per instruction per wave -> %.2f ticks per instruction per CU" % (waves, best, best / waves))

@@ -14,6 +14,7 @@ def run(nb, steps=20):
     else:
         xs = np.array([100 + 160.0 * (k % side) for k in range(nb)]); ys = np.array([100 + 160.0 * (k // side) for k in range(nb)])
     h = SimulationHandler(); h.set_option(_ffi.OPT_TIMING, 1)
+    if 'EGG_SPREAD' in os.environ: h.set_option(_ffi.OPT_THREADS_PER_PARTICLE, int(os.environ['EGG_SPREAD']))
     h.add_many(xs, ys, 50, 15)
     S = int(os.environ.get('EGG_S', '2')); Cc = int(os.environ.get('EGG_C', '3'))
     for _ in range(5): h.step(1 / 60, S, Cc)
@@ -24,7 +25,6 @@ def run(nb, steps=20):
     calls = buf[11]
     tot = sum(buf[k] for k in range(10))
     print("S=%d C=%d" % (S, Cc), "batches=%d kernel %.3f ms/step; tile-0 kernels=%d total ticks/kernel=%.0f rounds/kernel=%.0f" % (nb, kms / steps, calls, tot / calls, buf[10] / calls))
-    print("   dataflow loop of wave 0: load-wait %.0f ticks/kernel, solve+store %.0f, busy iterations %.0f, idle iterations %.0f" % (buf[12] / calls, buf[13] / calls, buf[14] / calls, buf[15] / calls))
     for k in range(10): print("   %-10s %10.0f ticks/kernel  %5.1f%%" % (names[k], buf[k] / calls, 100.0 * buf[k] / tot))
 if __name__ == "__main__":
     for nb in [int(a) for a in sys.argv[1:]] or [1]: run(nb)

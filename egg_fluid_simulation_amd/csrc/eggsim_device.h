@@ -34,7 +34,7 @@ struct EggStepArgs {
     const double *atom_fd;            // 2 * sqrt(batch radius) (L:1454, L:1790)
     const int32_t *atom_claim;   // int4 {lo_x, lo_y, hi_x, hi_y}: cells the atom's particles may occupy this step
     int32_t *atom_aabb_out;      // int4: cells occupied at the end of the step
-    int32_t *atom_fail;          // set to 1 when a particle of the atom left its claim
+    int32_t *atom_fail;          // cleared when the atom's tile starts, set to 1 when a particle of the atom left its claim
     int32_t *atom_disp_out;      // int4: max particle travel in the LAST sub-step towards +x, -x, +y, -y (1/16 px)
     // tiles: independent groups of atoms, one workgroup each
     const int32_t *tile_atom_begin;  // [n_tiles + 1] into tile_atoms
@@ -54,6 +54,7 @@ struct EggStepArgs {
     int32_t lcap;      // visit-list entries per pass (capacity)
     int32_t spin_sleep;  // 1: idle waves of the pair dataflow sleep between polls (many tiles per CU)
     EggStatus *status;
+    EggStatus *status_next;  // the other status block: re-initialised by this launch for the next one
     unsigned char *scratch;  // egg_step_kernel_gl / _gs: n_tiles slices of scratch_stride bytes
     unsigned long long scratch_stride;
 };

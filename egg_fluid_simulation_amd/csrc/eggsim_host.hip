@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -130,7 +131,12 @@ struct System {  // one particle type
     DevBuf<double> x[2], y[2], vx[2], vy[2], inv_mass, radius, mass_t;
     // atoms (host + device mirrors)
     std::vector<Atom> atoms;
-    DevBuf<int32_t> d_atom_offset, d_atom_count, d_atom_batch, d_atom_aabb;
+    DevBuf<int32_t> d_atom_offset, d_atom_count, d_atom_batch;
+    // what a step launch reports, in ONE device buffer so that one copy brings it back: two status blocks
+    // (the launch writes one and re-initialises the other for the next launch), the atoms' end-of-step cell
+    // boxes, their last-sub-step travel
+    DevBuf<int32_t> d_out;
+    int parity = 0;  // status block of the most recent launch
     std::vector<Box> aabb;  // host copy of the atoms' occupied cells
     bool aabb_valid = false;
     bool aabb_on_device = false;  // d_atom_aabb holds the cells of the CURRENT positions (written by the last step)
@@ -138,7 +144,6 @@ struct System {  // one particle type
     bool claims_stale = false;  // a target moved since the tiles were formed
     std::vector<int32_t> disp;                  // per atom: max particle travel of the last step (+x,-x,+y,-y; 1/16 px)
     bool disp_valid = false;                    // fetched together with the boxes of the current positions
-    DevBuf<int32_t> d_atom_disp;
     bool swept = false;                          // some claim was extended along predicted motion
     std::vector<int> extra_margin;               // per batch: extra claim cells after a failed check (decays)
     DevBuf<int32_t> d_atom_fail;                 // per atom: a particle left the claim in the last launch
@@ -167,11 +172,16 @@ struct System {  // one particle type
     // parameters of the step the tiles are being formed for (claims are swept along the follow motion)
     double step_follow_compliance = 57.6, step_damping = 0.9;
     int step_substeps = 2;
-    EggStatus *d_status = nullptr;
-    EggStatus *h_status = nullptr;  // pinned
+    EggStatus *h_status = nullptr;  // the most recent launch's status block inside stage_down (pinned)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
+
+constexpr size_t kStatInts = 160;  // one status block, padded to a multiple of 16 bytes
+static_assert(sizeof(EggStatus) <= kStatInts * 4, "status block too small");
+inline EggStatus *d_stat(System &s, int parity) { return (EggStatus *)(s.d_out.p + parity * kStatInts); }
+inline int32_t *d_aabb(System &s) { return s.d_out.p + 2 * kStatInts; }
+inline int32_t *d_disp(System &s) { return s.d_out.p + 2 * kStatInts + 4 * s.atoms.size(); }
 
 }  // namespace
 
@@ -330,6 +340,20 @@ int append_particles(egg_handle *h, System &s, const ParticleTemplate &tp, int64
 
 // ------------------------------------------------------------------- atoms
 
+int reserve_out(egg_handle *h, System &s, size_t na);
+
+// End of a step launch: a step kernel runs for a fraction of a millisecond, and waking up from a blocking
+// wait costs a noticeable part of that, so poll the stream for a short while before blocking.
+hipError_t wait_step(hipStream_t stream) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0;; ++it) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e;
+        if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) break;
+    }
+    return hipStreamSynchronize(stream);
+}
+
 int upload_atoms(egg_handle *h, int which) {
     System &s = h->sys[which];
     if (s.atoms_dirty) {
@@ -355,9 +379,11 @@ int upload_atoms(egg_handle *h, int which) {
         HIP_TRY(h, s.d_atom_offset.reserve(na + 1, false, s.stream));
         HIP_TRY(h, s.d_atom_count.reserve(na + 1, false, s.stream));
         HIP_TRY(h, s.d_atom_batch.reserve(na + 1, false, s.stream));
-        HIP_TRY(h, s.d_atom_aabb.reserve(4 * na + 4, false, s.stream));
+        {
+            int rc = reserve_out(h, s, na);
+            if (rc != EGG_OK) return rc;
+        }
         HIP_TRY(h, s.d_atom_fail.reserve(na + 1, false, s.stream));
-        HIP_TRY(h, s.d_atom_disp.reserve(4 * na + 4, false, s.stream));
         if (na) {
             HIP_TRY(h, hipMemcpy(s.d_atom_offset.p, o.data(), na * 4, hipMemcpyHostToDevice));
             HIP_TRY(h, hipMemcpy(s.d_atom_count.p, c.data(), na * 4, hipMemcpyHostToDevice));
@@ -426,10 +452,10 @@ int retile(egg_handle *h, int which) {
     s.tiled_cell_size = cell;
     if (!s.aabb_valid) {
         hipLaunchKernelGGL(egg_atom_bounds_kernel, dim3((unsigned)na), dim3(EGG_WAVE), 0, s.stream, s.x[s.cur].p,
-                           s.y[s.cur].p, s.d_atom_offset.p, s.d_atom_count.p, (int)na, cell, s.d_atom_aabb.p);
+                           s.y[s.cur].p, s.d_atom_offset.p, s.d_atom_count.p, (int)na, cell, d_aabb(s));
         HIP_TRY(h, hipGetLastError());
         s.aabb.resize(na);
-        HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), s.d_atom_aabb.p, na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), d_aabb(s), na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(h, hipStreamSynchronize(s.stream));
         s.aabb_valid = true;
         s.disp_valid = false;
@@ -723,11 +749,8 @@ Env make_env(const egg_config &c, double sub_delta, int64_t n) {
 int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     System &s = h->sys[which];
     if (s.n == 0 || s.classes.empty()) return EGG_OK;
-    EggStatus init;
-    memset(&init, 0, sizeof init);
-    init.min_slack = std::numeric_limits<int32_t>::max();
-    *s.h_status = init;
-    s.aabb_on_device = false;  // the launch overwrites d_atom_aabb
+    s.parity ^= 1;  // this launch's status block; it re-initialises the other one for the next launch
+    s.aabb_on_device = false;  // the launch overwrites the atoms' boxes
     s.out_copied = false;
     const size_t na = s.atoms.size();
     if (s.meta_dirty) {
@@ -753,8 +776,6 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         HIP_TRY(h, hipMemcpyAsync(s.d_meta.p, b, bytes, hipMemcpyHostToDevice, s.stream));
         s.meta_dirty = false;
     }
-    HIP_TRY(h, hipMemcpyAsync(s.d_status, s.h_status, sizeof(EggStatus), hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(h, hipMemsetAsync(s.d_atom_fail.p, 0, (na + 1) * sizeof(int32_t), s.stream));
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev0, s.stream));
     for (const LaunchClass &lc : s.classes) {
         EggStepArgs A;
@@ -777,9 +798,9 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.atom_ty = (const double *)(s.d_meta.p + s.meta_off_ty);
         A.atom_fd = (const double *)(s.d_meta.p + s.meta_off_fd);
         A.atom_claim = (const int32_t *)(s.d_meta.p + s.meta_off_claim);
-        A.atom_aabb_out = s.d_atom_aabb.p;
+        A.atom_aabb_out = d_aabb(s);
         A.atom_fail = s.d_atom_fail.p;
-        A.atom_disp_out = s.d_atom_disp.p;
+        A.atom_disp_out = d_disp(s);
         A.tile_atom_begin = (const int32_t *)(s.d_meta.p + s.meta_off_tbegin) + lc.first_tile;
         A.tile_atoms = (const int32_t *)(s.d_meta.p + s.meta_off_tatoms);
         A.n_tiles = lc.n_tiles;
@@ -802,7 +823,8 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         // more tiles than the chip can hold at one per CU: idle waves yield their issue slots
         A.spin_sleep = (h->opt_spin_sleep < 0) ? ((lc.n_tiles > 2 * h->prop.multiProcessorCount || lc.global_state) ? 1 : 0)
                                                : h->opt_spin_sleep;
-        A.status = s.d_status;
+        A.status = d_stat(s, s.parity);
+        A.status_next = d_stat(s, s.parity ^ 1);
         A.scratch = s.d_scratch.p + lc.scratch_offset;
         A.scratch_stride = lc.scratch_stride;
         const dim3 grid((unsigned)lc.n_tiles), block((unsigned)lc.threads);
@@ -820,15 +842,14 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         h->stats.kernel_launches++;
     }
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev1, s.stream));
-    HIP_TRY(h, hipMemcpyAsync(s.h_status, s.d_status, sizeof(EggStatus), hipMemcpyDeviceToHost, s.stream));
-    if (na && na <= 65536) {
-        // the atoms' end-of-step cell boxes and last-sub-step travel ride back behind the status: the
-        // next tiling (every step while targets move) then needs no further round trip
-        HIP_TRY(h, s.stage_down.reserve(na * 32));
-        HIP_TRY(h, hipMemcpyAsync(s.stage_down.p, s.d_atom_aabb.p, na * 16, hipMemcpyDeviceToHost, s.stream));
-        HIP_TRY(h, hipMemcpyAsync(s.stage_down.p + na * 16, s.d_atom_disp.p, na * 16, hipMemcpyDeviceToHost, s.stream));
-        s.out_copied = true;
-    }
+    // one copy brings back the status blocks and, behind them, the atoms' end-of-step cell boxes and
+    // last-sub-step travel: the next tiling (every step while targets move) then needs no further round trip
+    const bool with_boxes = na && na <= 65536;
+    const size_t bytes = (2 * kStatInts + (with_boxes ? 8 * na : 0)) * sizeof(int32_t);
+    HIP_TRY(h, s.stage_down.reserve(bytes));
+    HIP_TRY(h, hipMemcpyAsync(s.stage_down.p, s.d_out.p, bytes, hipMemcpyDeviceToHost, s.stream));
+    s.h_status = (EggStatus *)(s.stage_down.p + (size_t)s.parity * kStatInts * sizeof(int32_t));
+    s.out_copied = with_boxes;
     return EGG_OK;
 }
 
@@ -921,7 +942,7 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
         for (int w = 0; w < 2; ++w) {
             System &s = h->sys[w];
             if (s.n == 0 || s.classes.empty()) continue;
-            HIP_TRY(h, hipStreamSynchronize(s.stream));
+            HIP_TRY(h, wait_step(s.stream));
             if (h->opt_timing) {
                 float t = 0;
                 HIP_TRY(h, hipEventElapsedTime(&t, s.ev0, s.ev1));
@@ -1007,8 +1028,9 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                 const size_t na = s.atoms.size();
                 s.aabb.resize(na);
                 s.disp.resize(4 * na);
-                memcpy(s.aabb.data(), s.stage_down.p, na * 16);
-                memcpy(s.disp.data(), s.stage_down.p + na * 16, na * 16);
+                const unsigned char *boxes = s.stage_down.p + 2 * kStatInts * sizeof(int32_t);
+                memcpy(s.aabb.data(), boxes, na * 16);
+                memcpy(s.disp.data(), boxes + na * 16, na * 16);
                 s.aabb_valid = s.disp_valid = true;
             } else {
                 s.aabb_valid = false;  // fetched on demand
@@ -1048,14 +1070,28 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
     }
 }
 
+// device buffer for `na` atoms; a fresh allocation gets both status blocks initialised (afterwards every
+// launch re-initialises the block the next launch will use)
+int reserve_out(egg_handle *h, System &s, size_t na) {
+    const int32_t *before = s.d_out.p;
+    HIP_TRY(h, s.d_out.reserve(2 * kStatInts + 8 * na + 8, false, s.stream));
+    if (s.d_out.p != before) {
+        EggStatus init;
+        memset(&init, 0, sizeof init);
+        init.min_slack = std::numeric_limits<int32_t>::max();
+        for (int p = 0; p < 2; ++p) HIP_TRY(h, hipMemcpy(d_stat(s, p), &init, sizeof init, hipMemcpyHostToDevice));
+    }
+    return EGG_OK;
+}
+
 int fetch_end_aabb(egg_handle *h, System &s) {
     // after a committed step d_atom_aabb holds the atoms' cells at the new positions
     const size_t na = s.atoms.size();
     s.aabb.resize(na);
     s.disp.resize(4 * na);
     if (na) {
-        HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), s.d_atom_aabb.p, na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
-        HIP_TRY(h, hipMemcpyAsync(s.disp.data(), s.d_atom_disp.p, 4 * na * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), d_aabb(s), na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(h, hipMemcpyAsync(s.disp.data(), d_disp(s), 4 * na * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(h, hipStreamSynchronize(s.stream));
     }
     s.aabb_valid = true;
@@ -1140,13 +1176,13 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
         s.margin = h->opt_margin;
         bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreate(&s.ev0) == hipSuccess && hipEventCreate(&s.ev1) == hipSuccess &&
-                  hipMalloc((void **)&s.d_status, sizeof(EggStatus)) == hipSuccess &&
-                  hipHostMalloc((void **)&s.h_status, sizeof(EggStatus), hipHostMallocDefault) == hipSuccess;
+                  s.stage_down.reserve(2 * kStatInts * sizeof(int32_t)) == hipSuccess && reserve_out(h, s, 0) == EGG_OK;
         if (!ok) {
             egg_destroy(h);
             return fail(nullptr, EGG_ERR_DEVICE, "device resource allocation failed");
         }
-        memset(s.h_status, 0, sizeof(EggStatus));
+        memset(s.stage_down.p, 0, 2 * kStatInts * sizeof(int32_t));
+        s.h_status = (EggStatus *)s.stage_down.p;
     }
     // the reference primes its environments with _step(0, 1, 1) on zero particles (L:562); the
     // observable effect is that mass/radius of particles added later are not re-derived
@@ -1168,8 +1204,6 @@ void egg_destroy(egg_handle *h) {
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];
         if (s.stream) (void)hipStreamSynchronize(s.stream);
-        if (s.d_status) (void)hipFree(s.d_status);
-        if (s.h_status) (void)hipHostFree(s.h_status);
         if (s.ev0) (void)hipEventDestroy(s.ev0);
         if (s.ev1) (void)hipEventDestroy(s.ev1);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -1507,11 +1541,11 @@ int egg_get_bounds_many(egg_handle *h, int64_t n, const int64_t *ids, double *lo
         }
         if (!s.aabb_valid && na) {
             hipLaunchKernelGGL(egg_atom_bounds_kernel, dim3((unsigned)na), dim3(EGG_WAVE), 0, s.stream, s.x[s.cur].p,
-                               s.y[s.cur].p, s.d_atom_offset.p, s.d_atom_count.p, (int)na, cell[w], s.d_atom_aabb.p);
+                               s.y[s.cur].p, s.d_atom_offset.p, s.d_atom_count.p, (int)na, cell[w], d_aabb(s));
             HIP_TRY(h, hipGetLastError());
             h->stats.kernel_launches++;
             s.aabb.resize(na);
-            HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), s.d_atom_aabb.p, na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(h, hipMemcpyAsync(s.aabb.data(), d_aabb(s), na * sizeof(Box), hipMemcpyDeviceToHost, s.stream));
             HIP_TRY(h, hipStreamSynchronize(s.stream));
             // these are the cells of the CURRENT positions at the CURRENT cell size
             s.aabb_valid = true;

@@ -705,11 +705,20 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     const int a_begin = A.tile_atom_begin[tile];
     const int na = A.tile_atom_begin[tile + 1] - a_begin;
     t.na = na;
+    if (tile == 0 && A.status_next) {
+        // nothing touches the other status block while this launch runs (the host has read it, the next
+        // launch has not started): give it its initial state, so that the host uploads nothing per step
+        unsigned long long *q = (unsigned long long *)A.status_next;
+        for (int w = tid; w < (int)(sizeof(EggStatus) / 8); w += nthreads) q[w] = 0ull;
+        __syncthreads();
+        if (tid == 0) A.status_next->min_slack = 0x7FFFFFFF;
+    }
     if (tid == 0) {
         int off = 0;
         int ox = 0x7FFFFFFF, oy = 0x7FFFFFFF, hx = -0x7FFFFFFF, hy = -0x7FFFFFFF;
         for (int k = 0; k < na; ++k) {
             int atom = A.tile_atoms[a_begin + k];
+            A.atom_fail[atom] = 0;
             t.aoff[k] = off;
             off += A.atom_count[atom];
             for (int q = 0; q < 4; ++q) t.aclaim[4 * k + q] = A.atom_claim[4 * atom + q];
@@ -1170,9 +1179,15 @@ extern "C" __global__ void __launch_bounds__(256) egg_step_kernel(EggStepArgs A)
 // chip, six resident tiles per CU beat the spill-free build's four (measured: 2.75 -> 2.15 ms per
 // step at 4096 batches), while a tile that has its CU to itself is ~3 % slower
 extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_occ(EggStepArgs A) { egg_step_body<false, false>(A); }
-// up to 512 threads (256 registers per lane): tiles that have a CU to themselves run with three lanes per
-// particle, which build the visit lists column-wise; the pair scheduler still uses one lane per particle
-extern "C" __global__ void __launch_bounds__(512) egg_step_kernel_wide(EggStepArgs A) { egg_step_body<false, false>(A); }
+// up to 512 threads: tiles that have a CU to themselves run with three lanes per particle, which build the
+// visit lists column-wise; the pair scheduler still uses one lane per particle.  Registers are capped at
+// 168 (three waves per SIMD): the two waves per SIMD of such a workgroup then leave room for a wave of the
+// OTHER particle type's launch, which runs concurrently on its own stream -- uncapped (186 registers)
+// the yolk tiles waited for the white tiles to finish (+50 us per step in config 2).
+extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3)))
+egg_step_kernel_wide(EggStepArgs A) {
+    egg_step_body<false, false>(A);
+}
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true, false>(A); }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs(EggStepArgs A) { egg_step_body<true, true>(A); }
 

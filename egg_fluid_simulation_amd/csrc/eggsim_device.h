@@ -53,6 +53,7 @@ struct EggStepArgs {
     int32_t use_grid;  // 1: cells are a dense grid over the tile's claim box, 0: open-addressing hash
     int32_t lcap;      // visit-list entries per pass (capacity)
     int32_t spin_sleep;  // 1: idle waves of the pair dataflow sleep between polls (many tiles per CU)
+    int32_t pair_cache;  // 1: LDS holds lcap more 16-byte records (per-pair projection terms, see Tile::pinv)
     EggStatus *status;
     EggStatus *status_next;  // the other status block: re-initialised by this launch for the next one
     unsigned char *scratch;  // egg_step_kernel_gl / _gs: n_tiles slices of scratch_stride bytes
@@ -75,7 +76,7 @@ static inline size_t egg_step_scratch_bytes(int lcap, int single_tile) {
 
 // dynamic LDS bytes the step kernel carves for the geometry above (must match eggsim_step.hip)
 static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_grid, int lcap, int single_tile,
-                                        int global_lists, int threads) {
+                                        int global_lists, int threads, int pair_cache = 0) {
     size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, l = (size_t)lcap;
     size_t b = 0;
     b += 2 * egg_align16(n * 16);            // pos wr
@@ -88,6 +89,7 @@ static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_gr
     b += egg_align16((n + 1) * 4);           // inc_off
     b += 2 * egg_align16(n * 4);             // fill done
     if (!global_lists) b += 2 * egg_align16(l * 4);  // own_pack inc_tmp
+    if (!global_lists && pair_cache) b += egg_align16(l * 16);  // pinv
     b += egg_align16(a * 4 * 4);             // aclaim
     b += egg_align16((a + 1) * 4);           // aoff
     b += 2 * egg_align16(a * 4);             // abatch aglob

@@ -120,6 +120,7 @@ struct LaunchClass {  // tiles of similar size share a launch (uniform LDS geome
     int global_state = 0;  // everything in the scratch buffer (islands too large for LDS)
     int threads = 0;       // workgroup size
     int wide = 0;          // three lanes per particle for the list-building phases (egg_step_kernel_wide)
+    int pair_cache = 0;    // per-pair projection terms cached in LDS (16 B per list entry)
     size_t scratch_stride = 0;
     size_t lds = 0, scratch_offset = 0;
 };
@@ -703,6 +704,14 @@ int retile(egg_handle *h, int which) {
                 threads = wide_threads;
                 lc.wide = 1;
             }
+            // room to spare (few tiles per CU): cache the position-independent terms of every pair
+            const size_t with_cache = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0,
+                                                         threads, 1);
+            const int tiles_per_cu = (lc.n_tiles + h->prop.multiProcessorCount - 1) / h->prop.multiProcessorCount;
+            if (with_cache <= h->lds_limit && with_cache <= 64 * 1024 && (size_t)tiles_per_cu * with_cache <= 96 * 1024) {
+                lc.pair_cache = 1;
+                lc.lds = with_cache;
+            }
         }
         lc.threads = threads;
         if (lc.global_lists) {
@@ -823,6 +832,7 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         // more tiles than the chip can hold at one per CU: idle waves yield their issue slots
         A.spin_sleep = (h->opt_spin_sleep < 0) ? ((lc.n_tiles > 2 * h->prop.multiProcessorCount || lc.global_state) ? 1 : 0)
                                                : h->opt_spin_sleep;
+        A.pair_cache = lc.pair_cache;
         A.status = d_stat(s, s.parity);
         A.status_next = d_stat(s, s.parity ^ 1);
         A.scratch = s.d_scratch.p + lc.scratch_offset;

@@ -75,6 +75,9 @@ struct Tile {
     uint32_t *own_pack;   // [lcap]        visit lists: other | rank of the pair in other's sequence << 16
                           //               (rank 0 until the rank pass has run)
     uint32_t *inc_tmp;    // [lcap]        scratch: incoming (self | visit-list position << 16)
+    double2 *pinv;        // [lcap] or null: per visit entry (refined reciprocal of the pair's divisor, its minimum
+                          //               distance): the position-independent part of the projection, computed
+                          //               by all lanes when the lists are ranked instead of by the serial scheduler
     int32_t *aclaim, *aoff, *abatch, *aglob, *aaabb, *adisp;
     int32_t *sc;  // scalars: 2 particle count; 3 origin x; 4 origin y; 5 misc; 6 gw; 7 gh; 8.. scan carries
     uint16_t *hitems_b;   // [2][nmax]     particles sorted by cell, ascending index inside a cell
@@ -289,11 +292,13 @@ __device__ __forceinline__ bool pair_needs_reference(double2 wra, double2 wrb, d
 // denominator; numerators must be non-zero normal numbers (a zero numerator would lose its sign in the
 // hand expansion).  Anything else -- including NaN, which fails every comparison -- takes the
 // reference path from the unchanged inputs.
+template <bool CACHED>
 __device__ __forceinline__ void project_pair(const Tile &t, int a, int b, bool slow, double2 &pa, double2 &pb,
-                                             double2 wra, double2 wrb, double overlap, double compliance, double eps) {
+                                             double2 wra, double2 wrb, double2 cached, double overlap, double compliance,
+                                             double eps) {
     const double dx = pb.x - pa.x, dy = pb.y - pa.y;
     const double d2 = dx * dx + dy * dy;
-    const double min_distance = overlap * (wra.y + wrb.y);
+    const double min_distance = CACHED ? cached.y : overlap * (wra.y + wrb.y);
     const double md2 = min_distance * min_distance;
     if (((int)(d2 <= md2) | (int)slow) != 0) {
         double current, r_current;
@@ -304,7 +309,7 @@ __device__ __forceinline__ void project_pair(const Tile &t, int a, int b, bool s
         if (__builtin_expect(fast, 1)) {
             const double wa = wra.x, wb = wrb.x;
             const double divisor = (wa + wb) + compliance;
-            const double r_divisor = egg_rcp_refined(divisor);
+            const double r_divisor = CACHED ? cached.x : egg_rcp_refined(divisor);
             const double nx = egg_div_with_rcp(dx, current, r_current);
             const double ny = egg_div_with_rcp(dy, current, r_current);
             double correction = egg_div_with_rcp(-violation, divisor, r_divisor);
@@ -503,7 +508,7 @@ struct StatePtr<true, T> {
     using type = T *;
 };
 
-template <bool GLOBAL_STATE>
+template <bool GLOBAL_STATE, bool CACHED>
 __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, int nthreads, double overlap,
                                        double compliance, double eps, int total, int spin_sleep,
                                        unsigned int &spins_out) {
@@ -543,7 +548,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
         // without a pending pair waits for a counter value that never comes.
         uint32_t want_a, want_b;
         P32 p_db;
-        PD2 p_pb, p_wb;
+        PD2 p_pb, p_wb, p_pc = (PD2)t.pinv;
         int i_next;
         auto aim = [&]() {
             const bool live = k < no;
@@ -554,8 +559,9 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
             p_pb = (PD2)&t.pos[b];
             p_wb = (PD2)&t.wr[b];
             i_next = min(o0 + k + 1, t.lcap - 1);
+            if (CACHED) p_pc = (PD2)&t.pinv[min(o0 + k, t.lcap - 1)];
             if (!GLOBAL_STATE)  // keep them in registers; do not re-derive them from `ent` in the loop
-                __asm__ volatile("" : "+v"(want_a), "+v"(want_b), "+v"(p_db), "+v"(p_pb), "+v"(p_wb), "+v"(i_next));
+                __asm__ volatile("" : "+v"(want_a), "+v"(want_b), "+v"(p_db), "+v"(p_pb), "+v"(p_wb), "+v"(i_next), "+v"(p_pc));
         };
         int no_live = no;  // == no unless the hang guard fires
         aim();
@@ -575,16 +581,21 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
 #endif
             }
             const egg_d2 va = *p_pa, vb = *p_pb, vw = *p_wb;
+            egg_d2 vc = {0.0, 0.0};
+            if (CACHED) vc = *p_pc;
             double2 pa = make_double2(va.x, va.y);
             double2 pb = make_double2(vb.x, vb.y);
             const double2 wrb = make_double2(vw.x, vw.y);
+            const double2 pc = make_double2(vc.x, vc.y);
             const uint32_t ent_next = t.own_pack[i_next];
             // consume the speculative loads here so that they are issued back to back with the
             // counters instead of being sunk behind the readiness branch (one LDS latency, not four)
-            __asm__ volatile("" ::"v"(pa.x), "v"(pa.y), "v"(pb.x), "v"(pb.y), "v"(wrb.x), "v"(wrb.y), "v"(ent_next));
+            __asm__ volatile("" ::"v"(pa.x), "v"(pa.y), "v"(pb.x), "v"(pb.y), "v"(wrb.x), "v"(wrb.y), "v"(ent_next), "v"(pc.x),
+                             "v"(pc.y));
             const bool ready = ((int)(da == want_a) & (int)(db == want_b)) != 0;
             if (ready) {
-                project_pair(t, a, (int)(ent & EGG_IDX), (ent & 0x8000u) != 0, pa, pb, wra, wrb, overlap, compliance, eps);
+                project_pair<CACHED>(t, a, (int)(ent & EGG_IDX), (ent & 0x8000u) != 0, pa, pb, wra, wrb, pc, overlap, compliance,
+                                     eps);
                 *p_pa = (egg_d2){pa.x, pa.y};
                 *p_pb = (egg_d2){pb.x, pb.y};
                 EGG_COMPILER_BARRIER();  // data first, then the counters that publish it
@@ -666,6 +677,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             t.own_pack = (uint32_t *)carve(p, l * 4);
             t.inc_tmp = (uint32_t *)carve(p, l * 4);
         }
+        t.pinv = (!GLOBAL_LISTS && A.pair_cache) ? (double2 *)carve(p, l * 16) : nullptr;
         t.aclaim = (int32_t *)carve(p, a * 4 * 4);
         t.aoff = (int32_t *)carve(p, (a + 1) * 4);
         t.abatch = (int32_t *)carve(p, a * 4);
@@ -1063,6 +1075,11 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 const uint32_t slow = pair_needs_reference(t.wr[cself], t.wr[i], A.overlap_factor, A.collision_compliance, eps)
                                           ? 0x8000u : 0u;
                 t.own_pack[e] = (uint32_t)i | slow | (rank << 16);
+                if (t.pinv) {
+                    const double2 ws = t.wr[cself], wo = t.wr[i];
+                    t.pinv[e] = make_double2(egg_rcp_refined((ws.x + wo.x) + A.collision_compliance),
+                                             A.overlap_factor * (ws.y + wo.y));
+                }
             }
             // pairs in which a particle is `other` of a smaller self come before its own visits
             for (int i = tid; i < n; i += nthreads) {
@@ -1076,8 +1093,10 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             PROF(6)  // transpose
             // -------------------------------------- dataflow execution of the pair projections
             unsigned int spins = 0;
-            int solved = execute_dataflow<GLOBAL_STATE>(t, cur, n, tid, nthreads, A.overlap_factor, A.collision_compliance, eps,
-                                          total, A.spin_sleep, spins);
+            int solved = t.pinv ? execute_dataflow<GLOBAL_STATE, true>(t, cur, n, tid, nthreads, A.overlap_factor,
+                                                                       A.collision_compliance, eps, total, A.spin_sleep, spins)
+                                : execute_dataflow<GLOBAL_STATE, false>(t, cur, n, tid, nthreads, A.overlap_factor,
+                                                                        A.collision_compliance, eps, total, A.spin_sleep, spins);
             spins_total += spins;
             __syncthreads();
             PROF(7)  // DAG
@@ -1306,7 +1325,7 @@ extern "C" __global__ void egg_microbench_kernel(int mode, int iters, int active
                 pa = lpos[lane];
                 pb = lpos[lane + 64];
             }
-            project_pair(t, lane, lane + 64, (iters & 0x40000000) != 0, pa, pb, wra, wrb, 2.0, 36.0, 1e-8);
+            project_pair<false>(t, lane, lane + 64, (iters & 0x40000000) != 0, pa, pb, wra, wrb, wra, 2.0, 36.0, 1e-8);
             if (mode == 1) {
                 lpos[lane] = pa;
                 lpos[lane + 64] = pb;

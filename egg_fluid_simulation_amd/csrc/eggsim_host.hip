@@ -198,7 +198,7 @@ struct egg_handle {
     egg_stats stats{};
     std::string error;
     int opt_margin = 2;
-    int opt_tile_target = 0;
+    int opt_tile_target = 60;  // islands smaller than a wave share one (a 15-particle yolk blob uses a quarter of its lanes)
     int opt_timing = 0;
     int opt_force_single = 0;
     int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
@@ -997,7 +997,9 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
             }
             if (st.fail_stall)
                 return fail(h, EGG_ERR_INTERNAL, "pair scheduler stalled (type %d, %s)", w,
-                            st.fail_stall == 2 ? "time limit reached" : "a particle's pair sequence did not finish");
+                            st.fail_stall == 2 ? "time limit reached"
+                            : st.fail_stall == 3 ? "workgroup narrower than the wide kernel needs"
+                                                 : "a particle's pair sequence did not finish");
             const bool single = s.single_tile || h->opt_force_single;
             if (!single) {
                 // budget check (L:1657-1658): the return can only fire if some pass visits more than

@@ -343,49 +343,9 @@ struct PassCtx {
 // so own(i) = { j > i in the 3x3 cells }, cells in loop order, ascending j inside a cell.
 // FILL also counts, per partner, how many selves visit it (t.done doubles as that counter until
 // the pair scheduler starts): the transposition below needs it and the atomic needs no return.
-template <bool FILL>
-__device__ inline int enum_fresh(const Tile &t, int cur, int i, uint32_t *dst) {
-    const uint32_t ki = t.ckey(cur)[i];
-    const uint16_t *items = t.hitems(cur);
-    uint32_t m[9];
-#pragma unroll
-    for (int s = 0; s < 9; ++s) m[s] = cell_meta(t, cur, (uint32_t)((int)ki + (s / 3 - 1) * 65536 + (s % 3 - 1)));
-    uint16_t it[9][4];
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        const int st = (int)(m[s] >> 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) it[s][q] = items[min(st + q, t.n - 1)];  // unconditional; masked by q < cn below
-    }
-    int count = 0;
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-        const int st = (int)(m[s] >> 16), cn = (int)(m[s] & 0xFFFFu);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q < cn && (int)it[s][q] > i) {
-                if (FILL) {
-                    dst[count] = (uint32_t)it[s][q] | ((uint32_t)i << 16);
-                    atomicAdd(&t.done[it[s][q]], 1u);
-                }
-                ++count;
-            }
-        for (int e = 4; e < cn; ++e) {
-            int j = items[st + e];
-            if (j > i) {
-                if (FILL) {
-                    dst[count] = (uint32_t)j | ((uint32_t)i << 16);
-                    atomicAdd(&t.done[j], 1u);
-                }
-                ++count;
-            }
-        }
-    }
-    return count;
-}
-
-// one column (x offset p - 1) of the same loop: the visit list of i is the concatenation of its three
-// columns, so three lanes can build it side by side when the workgroup has lanes to spare
+// One column (x offset p - 1) of the 3x3 loop: the visit list of i is the concatenation of its three
+// columns, so three lanes can build it side by side when the workgroup has lanes to spare (wide kernel);
+// otherwise one lane walks the columns in turn (enum_fresh below).
 template <bool FILL>
 __device__ inline int enum_fresh_column(const Tile &t, int cur, int i, int p, uint32_t *dst) {
     const uint32_t ki = t.ckey(cur)[i];
@@ -408,6 +368,15 @@ __device__ inline int enum_fresh_column(const Tile &t, int cur, int i, int p, ui
             }
         }
     }
+    return count;
+}
+
+// the whole neighbourhood, column after column (a fully unrolled nine-cell version with every load in
+// flight at once was ~5 % faster for a lone tile but cost 25-45 registers, i.e. a wave per SIMD)
+template <bool FILL>
+__device__ inline int enum_fresh(const Tile &t, int cur, int i, uint32_t *dst) {
+    int count = 0;
+    for (int p = 0; p < 3; ++p) count += enum_fresh_column<FILL>(t, cur, i, p, FILL ? dst + count : dst);
     return count;
 }
 
@@ -643,7 +612,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
 // algorithm, HBM/L2 latency on every access, workgroup-scope release/acquire around the dataflow
 // counters (global memory gives no issue-order guarantee).  Slow, but any island up to the index
 // limits (32766 particles, 60000 visited pairs per pass) is stepped exactly.
-template <bool GLOBAL_LISTS, bool GLOBAL_STATE>
+template <bool GLOBAL_LISTS, bool GLOBAL_STATE, bool WIDE = false>
 __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -812,7 +781,12 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
 
     // a workgroup with at least three lanes per particle builds the visit lists column-wise (launch
     // classes that have a CU almost to themselves get such workgroups, see the host's launch_type)
-    const int parts = (nthreads >= 3 * n) ? 3 : 1;
+    // (a compile-time property of the kernel variant: each variant carries only its own list builder)
+    const int parts = WIDE ? 3 : 1;
+    if (WIDE && nthreads < 3 * n) {  // the host sizes wide workgroups as 3 lanes per particle
+        if (tid == 0) atomicExch(&A.status->fail_stall, 3);
+        return;
+    }
     __shared__ uint32_t wtot[16];  // per-wave totals of the workgroup-wide prefix sums
 
     int cur = 0;
@@ -950,7 +924,8 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             } else if (ctx.stale) {
                 for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_stale<false>(t, ctx, i, nullptr);
             } else {
-                for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_fresh<false>(t, cur, i, nullptr);
+                for (int i = tid; i < n; i += nthreads)
+                    t.fill[i] = (uint32_t)enum_fresh<false>(t, cur, i, nullptr);
             }
             __syncthreads();
             PROF(3)  // visit count
@@ -1197,7 +1172,9 @@ extern "C" __global__ void __launch_bounds__(256) egg_step_kernel(EggStepArgs A)
 // the same with registers capped at 96 (5 waves per SIMD): when thousands of tiles queue for the
 // chip, six resident tiles per CU beat the spill-free build's four (measured: 2.75 -> 2.15 ms per
 // step at 4096 batches), while a tile that has its CU to itself is ~3 % slower
-extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_occ(EggStepArgs A) { egg_step_body<false, false>(A); }
+extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_occ(EggStepArgs A) {
+    egg_step_body<false, false>(A);
+}
 // up to 512 threads: tiles that have a CU to themselves run with three lanes per particle, which build the
 // visit lists column-wise; the pair scheduler still uses one lane per particle.  Registers are capped at
 // 168 (three waves per SIMD): the two waves per SIMD of such a workgroup then leave room for a wave of the
@@ -1205,7 +1182,7 @@ extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_occ(EggStep
 // the yolk tiles waited for the white tiles to finish (+50 us per step in config 2).
 extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3)))
 egg_step_kernel_wide(EggStepArgs A) {
-    egg_step_body<false, false>(A);
+    egg_step_body<false, false, true>(A);
 }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true, false>(A); }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs(EggStepArgs A) { egg_step_body<true, true>(A); }

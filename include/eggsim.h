@@ -196,7 +196,7 @@ int egg_selftest_arith(egg_handle *h, int64_t n_operand_pairs, uint64_t seed, in
 /* tuning knobs (not part of the reference surface) */
 enum {
     EGG_OPT_CLAIM_MARGIN_CELLS = 0, /* initial margin around an atom's cells when tiles are formed */
-    EGG_OPT_TILE_TARGET_PARTICLES,  /* pack independent islands into tiles up to this size (0 = one island per tile) */
+    EGG_OPT_TILE_TARGET_PARTICLES,  /* pack independent islands into tiles up to this size (0 = one island per tile; default 60: small islands share a wave) */
     EGG_OPT_TIMING,                 /* 1: record HIP events around the step kernels */
     EGG_OPT_FORCE_SINGLE_TILE,      /* 1: always run each type as one tile (exact budget path) */
     EGG_OPT_THREADS_PER_PARTICLE,   /* lanes per particle: 0 automatic (3 for tiles that have a CU to themselves: visit lists built column-wise), 1 or 3 forced */

@@ -118,7 +118,8 @@ def test_full_size_config2_properties(egg, oracle_mod):
     xs, ys = _grid(4096)
     h, o, ids = _run_both(egg, oracle_mod, xs, ys, 2, False)
     _assert_same_state(h, o)
-    assert h.stats()["n_tiles"] == [4096, 4096]
+    # 4096 white islands, one workgroup each; the 15-particle yolk islands share workgroups four by four
+    assert h.stats()["n_tiles"] == [4096, 1024]
     # determinism: a second handler reproduces the state bit for bit
     h2 = egg.SimulationHandler()
     h2.add_many(xs, ys, 50, 15)
@@ -134,7 +135,7 @@ def test_result_is_independent_of_tiling(egg):
     from egg_fluid_simulation_amd import _ffi
     xs, ys = _grid(36)  # the forced single tile (5652 white particles) runs in the global-memory-state kernel
     ref = None
-    for opts in ({}, {_ffi.OPT_TILE_TARGET_PARTICLES: 700}, {_ffi.OPT_CLAIM_MARGIN_CELLS: 6},
+    for opts in ({}, {_ffi.OPT_TILE_TARGET_PARTICLES: 0}, {_ffi.OPT_TILE_TARGET_PARTICLES: 700}, {_ffi.OPT_CLAIM_MARGIN_CELLS: 6},
                  {_ffi.OPT_FORCE_SINGLE_TILE: 1}):
         h = egg.SimulationHandler()
         for k, v in opts.items():

@@ -53,6 +53,7 @@ struct EggStepArgs {
     int32_t use_grid;  // 1: cells are a dense grid over the tile's claim box, 0: open-addressing hash
     int32_t lcap;      // visit-list entries per pass (capacity)
     int32_t spin_sleep;  // 1: idle waves of the pair dataflow sleep between polls (many tiles per CU)
+    int32_t gens;        // hash generations kept alive (2; n_substeps when there is one collision pass per sub-step)
     int32_t pair_cache;  // 1: LDS holds lcap more 16-byte records (per-pair projection terms, see Tile::pinv)
     EggStatus *status;
     EggStatus *status_next;  // the other status block: re-initialised by this launch for the next one
@@ -69,23 +70,23 @@ static inline size_t egg_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-static inline size_t egg_step_scratch_bytes(int lcap, int single_tile) {
-    size_t l = (size_t)lcap;
-    return 2 * ((l * 4 + 15) & ~(size_t)15) + ((((single_tile ? 2 : 0) * l * 2) + 15) & ~(size_t)15);
+static inline size_t egg_step_scratch_bytes(int lcap, int single_tile, int gens = 2) {
+    size_t l = (size_t)lcap, g = (size_t)(gens < 2 ? 2 : gens);
+    return 2 * ((l * 4 + 15) & ~(size_t)15) + ((((single_tile ? g : 0) * l * 2) + 15) & ~(size_t)15);
 }
 
 // dynamic LDS bytes the step kernel carves for the geometry above (must match eggsim_step.hip)
 static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_grid, int lcap, int single_tile,
-                                        int global_lists, int threads, int pair_cache = 0) {
-    size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, l = (size_t)lcap;
+                                        int global_lists, int threads, int pair_cache = 0, int gens = 2) {
+    size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, l = (size_t)lcap, g = (size_t)(gens < 2 ? 2 : gens);
     size_t b = 0;
     b += 2 * egg_align16(n * 16);            // pos wr
     b += 2 * egg_align16(nmax > threads ? n * 16 : 0);  // prev vel (registers otherwise)
     b += 3 * egg_align16(a * 8);             // atx aty afd
-    b += egg_align16(2 * n * 4);             // ckey[2]
-    b += egg_align16(2 * c * 4);             // cell[2]
-    b += egg_align16(use_grid ? 0 : 2 * c * 4);  // hkeys[2]
-    b += egg_align16((single_tile ? 2 : 1) * (n + 1) * 4);  // own_off
+    b += egg_align16(g * n * 4);             // ckey[gens]
+    b += egg_align16(g * c * 4);             // cell[gens]
+    b += egg_align16(use_grid ? 0 : g * c * 4);  // hkeys[gens]
+    b += egg_align16((single_tile ? g : 1) * (n + 1) * 4);  // own_off
     b += egg_align16((n + 1) * 4);           // inc_off
     b += 2 * egg_align16(n * 4);             // fill done
     if (!global_lists) b += 2 * egg_align16(l * 4);  // own_pack inc_tmp
@@ -95,9 +96,9 @@ static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_gr
     b += 2 * egg_align16(a * 4);             // abatch aglob
     b += 2 * egg_align16(a * 4 * 4);         // aaabb adisp
     b += egg_align16(16 * 4);                // scalars
-    b += egg_align16(2 * n * 2);             // hitems[2]
+    b += egg_align16(g * n * 2);             // hitems[gens]
     b += 3 * egg_align16(n * 2);             // pslot aslot nlo
-    if (!global_lists) b += egg_align16(single_tile ? 2 * l * 2 : 0);  // own_ent (exact-budget mode)
+    if (!global_lists) b += egg_align16(single_tile ? g * l * 2 : 0);  // own_ent (exact-budget mode)
     return b;
 }
 

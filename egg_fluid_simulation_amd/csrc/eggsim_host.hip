@@ -26,6 +26,9 @@ extern "C" __global__ void egg_step_kernel(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_occ(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_wide(EggStepArgs A);
+extern "C" __global__ void egg_step_kernel_mg(EggStepArgs A);
+extern "C" __global__ void egg_step_kernel_gl_mg(EggStepArgs A);
+extern "C" __global__ void egg_step_kernel_gs_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gs(EggStepArgs A);
 extern "C" __global__ void egg_selftest_arith_kernel(unsigned long long, int, unsigned long long *);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
@@ -138,6 +141,7 @@ struct System {  // one particle type
     // boxes, their last-sub-step travel
     DevBuf<int32_t> d_out;
     int parity = 0;  // status block of the most recent launch
+    int gens = 2;    // hash generations the kernel keeps (n_substeps when n_collision_steps == 1, see PassCtx)
     std::vector<Box> aabb;  // host copy of the atoms' occupied cells
     bool aabb_valid = false;
     bool aabb_on_device = false;  // d_atom_aabb holds the cells of the CURRENT positions (written by the last step)
@@ -669,7 +673,7 @@ int retile(egg_handle *h, int which) {
         lcap = (lcap + 7) & ~(size_t)7;
         lc.lcap = (int)lcap;
         int threads = egg_step_threads(lc.nmax, 1);
-        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0, threads);
+        lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0, threads, 0, s.gens);
         bool want_global_state = h->opt_force_global_state != 0;
         if (!want_global_state && (lc.lds > h->lds_limit || lc.lds > 64 * 1024 || threads > 256)) {
             // dense or large tiles: particle state stays in LDS, the visit lists go to global memory
@@ -677,7 +681,7 @@ int retile(egg_handle *h, int which) {
             lcap = std::max<size_t>({lcap, (size_t)(32.0 * lc.nmax), s.list_min});
             lcap = std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxListEntries);
             lc.lcap = (int)lcap;
-            lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1, threads);
+            lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1, threads, 0, s.gens);
             if (lc.lds > h->lds_limit) want_global_state = true;
         }
         if (want_global_state) {
@@ -686,16 +690,16 @@ int retile(egg_handle *h, int which) {
             lc.global_lists = lc.global_state = 1;
             lcap = std::max<size_t>({lcap, (size_t)(32.0 * lc.nmax), s.list_min});
             lc.lcap = (int)std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxListEntries);
-            const size_t state = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1, threads);
-            lc.scratch_stride = ((state + 255) & ~(size_t)255) + egg_step_scratch_bytes(lc.lcap, single ? 1 : 0) + 256;
+            const size_t state = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1, threads, 0, s.gens);
+            lc.scratch_stride = ((state + 255) & ~(size_t)255) + egg_step_scratch_bytes(lc.lcap, single ? 1 : 0, s.gens) + 256;
             lc.lds = 0;
         } else if (lc.global_lists) {
-            lc.scratch_stride = (egg_step_scratch_bytes(lc.lcap, single ? 1 : 0) + 255) & ~(size_t)255;
+            lc.scratch_stride = (egg_step_scratch_bytes(lc.lcap, single ? 1 : 0, s.gens) + 255) & ~(size_t)255;
         }
         // A tile that has a CU (almost) to itself leaves most of the CU's issue slots idle: give it three
         // lanes per particle, which the kernel uses to build the visit lists column-wise.  With more
         // tiles than that, one lane per particle keeps the most tiles resident.
-        if (!lc.global_lists && !lc.global_state) {
+        if (!lc.global_lists && !lc.global_state && s.gens <= 2) {
             int spread = h->opt_spread;
             // (two such workgroups do not fit one CU's register file, so: at most one tile per CU)
             if (spread <= 0) spread = (lc.n_tiles <= h->prop.multiProcessorCount) ? 3 : 1;
@@ -706,7 +710,7 @@ int retile(egg_handle *h, int which) {
             }
             // room to spare (few tiles per CU): cache the position-independent terms of every pair
             const size_t with_cache = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0,
-                                                         threads, 1);
+                                                         threads, 1, s.gens);
             const int tiles_per_cu = (lc.n_tiles + h->prop.multiProcessorCount - 1) / h->prop.multiProcessorCount;
             if (with_cache <= h->lds_limit && with_cache <= 64 * 1024 && (size_t)tiles_per_cu * with_cache <= 96 * 1024) {
                 lc.pair_cache = 1;
@@ -833,12 +837,20 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         A.spin_sleep = (h->opt_spin_sleep < 0) ? ((lc.n_tiles > 2 * h->prop.multiProcessorCount || lc.global_state) ? 1 : 0)
                                                : h->opt_spin_sleep;
         A.pair_cache = lc.pair_cache;
+        A.gens = s.gens;
         A.status = d_stat(s, s.parity);
         A.status_next = d_stat(s, s.parity ^ 1);
         A.scratch = s.d_scratch.p + lc.scratch_offset;
         A.scratch_stride = lc.scratch_stride;
         const dim3 grid((unsigned)lc.n_tiles), block((unsigned)lc.threads);
-        if (lc.global_state)
+        if (s.gens > 2) {  // more than two hash generations: the variants with the general list builder
+            if (lc.global_state)
+                hipLaunchKernelGGL(egg_step_kernel_gs_mg, grid, block, 64, s.stream, A);
+            else if (lc.global_lists)
+                hipLaunchKernelGGL(egg_step_kernel_gl_mg, grid, block, lc.lds, s.stream, A);
+            else
+                hipLaunchKernelGGL(egg_step_kernel_mg, grid, block, lc.lds, s.stream, A);
+        } else if (lc.global_state)
             hipLaunchKernelGGL(egg_step_kernel_gs, grid, block, 64, s.stream, A);
         else if (lc.global_lists)
             hipLaunchKernelGGL(egg_step_kernel_gl, grid, block, lc.lds, s.stream, A);
@@ -902,10 +914,17 @@ enum { kWhole = 0, kPrepare = 1, kBegin = 2, kEnd = 3 };
 
 int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  // L:1722-1989
     const double sub_delta = std::max(delta / S, h->sys[0].cfg.eps);
-    if (C == 1 && S >= 3)
+    // One collision pass per sub-step: the reference never clears its hash lists inside the step, so the
+    // kernel keeps one generation of cells per sub-step (PassCtx); the ring is sized for up to 8.
+    const int gens = (C == 1 && S >= 3) ? S : 2;
+    if (gens > 8)
         return fail(h, EGG_ERR_UNSUPPORTED,
-                    "n_collision_steps == 1 with n_substeps >= 3 (hash lists accumulating over more than one "
-                    "un-cleared pass) is not implemented on the device path");
+                    "n_collision_steps == 1 with n_substeps > 8 (more than 8 un-cleared hash generations)");
+    for (int w = 0; w < 2; ++w)
+        if (h->sys[w].gens != gens) {
+            h->sys[w].gens = gens;
+            h->sys[w].tiling_dirty = true;  // LDS geometry of the launch classes depends on it
+        }
     Env env[2];
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];
@@ -1177,6 +1196,10 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
             e = hipFuncSetAttribute((const void *)egg_step_kernel_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)egg_step_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_mg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_gl_mg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess) {
             h->lds_limit = want;
             break;

@@ -329,10 +329,19 @@ __device__ __forceinline__ void project_pair(const Tile &t, int a, int b, bool s
     }
 }
 
+// Hash generations.  The reference clears the cell lists and `collided` only BETWEEN the collision passes
+// of a sub-step (L:1905-1912), so the first pass of a later sub-step still sees the previous pass (Q3);
+// with a single collision pass per sub-step nothing is ever cleared inside a step and every sub-step
+// adds a generation.  Buffers form a ring of G; age 0 is this pass, age d the pass d rebuilds ago.
 struct PassCtx {
-    int cur;         // which buffer is "this pass"
-    int stale;       // previous pass's hash lists and collided set are still alive (Q3)
-    int prev_uncut;  // previous pass visited every adjacent pair (no budget cut)
+    int cur;         // buffer of this pass
+    int prev;        // buffer of the previous pass (age 1)
+    int live;        // older generations still alive (0 = fresh pass)
+    int G;           // ring size
+    int stale;       // live > 0
+    int prev_uncut;  // the previous pass visited every adjacent pair (no budget cut)
+    unsigned int cut_mask;  // bit d: the pass of age d was cut by the budget
+    __device__ int buf(int age) const { return (cur + G - age % G) % G; }
 };
 
 // ------------------------------------------------------------------ visit lists
@@ -385,8 +394,8 @@ __device__ inline bool in_prev(const Tile &t, const PassCtx &c, int i, int j, ui
     if (cell_slot(koj, koi) < 0) return false;  // never met in the previous (fresh) pass
     if (c.prev_uncut) return true;
     int lo = i < j ? i : j, hi = i < j ? j : i;
-    const uint32_t *off = t.own_off(c.cur ^ 1);
-    const uint16_t *ent = t.own_ent(c.cur ^ 1);
+    const uint32_t *off = t.own_off(c.prev);
+    const uint16_t *ent = t.own_ent(c.prev);
     for (uint32_t e = off[lo]; e < off[lo + 1]; ++e)
         if (ent[e] == (uint16_t)hi) return true;
     return false;
@@ -414,16 +423,16 @@ __device__ inline bool accept_stale(const Tile &t, const PassCtx &c, int i, int 
 
 template <bool FILL>
 __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_t *dst, int s0 = 0, int s1 = 9) {
-    const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.cur ^ 1);
+    const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.prev);
     const uint32_t kni = kn[i], koi = ko[i];
     int count = 0;
     for (int s = s0; s < s1; ++s) {
         const uint32_t nk = (uint32_t)((int)kni + (s / 3 - 1) * 65536 + (s % 3 - 1));
-        const uint32_t mo = cell_meta(t, c.cur ^ 1, nk), mn = cell_meta(t, c.cur, nk);
+        const uint32_t mo = cell_meta(t, c.prev, nk), mn = cell_meta(t, c.cur, nk);
 #pragma unroll
         for (int isnew = 0; isnew < 2; ++isnew) {
             const uint32_t m = isnew ? mn : mo;
-            const uint16_t *items = t.hitems(isnew ? c.cur : c.cur ^ 1);
+            const uint16_t *items = t.hitems(isnew ? c.cur : c.prev);
             const int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
             for (int e0 = 0; e0 < cn; e0 += 4) {
                 int j[4];
@@ -444,6 +453,76 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_
                         }
                         ++count;
                     }
+            }
+        }
+    }
+    return count;
+}
+
+// ---- more than two generations alive (one collision pass per sub-step, three or more sub-steps) ----
+// The same rules, stated over ages: a cell's list holds the oldest generation's entries first.
+
+// is {i, j} in `collided`?  It was attempted at the pass of age p iff one of them met an entry (of age >= p)
+// of the other in the 3x3 cells around the cell it was in at that pass; a pass the budget cut only counts
+// for what it actually visited.
+__device__ inline bool in_collided_multi(const Tile &t, const PassCtx &c, int i, int j) {
+    for (int p = 1; p <= c.live; ++p) {
+        const int bp = c.buf(p);
+        const uint32_t kpi = t.ckey(bp)[i], kpj = t.ckey(bp)[j];
+        bool adj = false;
+        for (int b = p; b <= c.live && !adj; ++b) {
+            const int bb = c.buf(b);
+            adj = cell_slot(t.ckey(bb)[j], kpi) >= 0 || cell_slot(t.ckey(bb)[i], kpj) >= 0;
+        }
+        if (!adj) continue;
+        if (!((c.cut_mask >> p) & 1u)) return true;
+        const uint32_t *off = t.own_off(bp);
+        const uint16_t *ent = t.own_ent(bp);
+        for (uint32_t e = off[i]; e < off[i + 1]; ++e)
+            if (ent[e] == (uint16_t)j) return true;
+        for (uint32_t e = off[j]; e < off[j + 1]; ++e)
+            if (ent[e] == (uint16_t)i) return true;
+    }
+    return false;
+}
+
+// does self i visit j when it meets j's entry of age d at 3x3 slot s?
+__device__ inline bool accept_multi(const Tile &t, const PassCtx &c, int i, int j, int s, int d, uint32_t kni) {
+    if (j == i) return false;
+    // j sits in i's attempt order once per generation that put it into the neighbourhood: first occurrence wins
+    for (int d2 = c.live; d2 >= 0; --d2) {
+        const int s2 = cell_slot(t.ckey(c.buf(d2))[j], kni);
+        if (s2 >= 0 && (s2 < s || (s2 == s && d2 > d))) return false;
+    }
+    if (in_collided_multi(t, c, i, j)) return false;
+    if (j < i) {  // j's loop ran first in this pass: did it meet any entry of i?
+        const uint32_t knj = t.ckey(c.cur)[j];
+        for (int a = 0; a <= c.live; ++a)
+            if (cell_slot(t.ckey(c.buf(a))[i], knj) >= 0) return false;
+    }
+    return true;
+}
+
+template <bool FILL>
+__device__ inline int enum_stale_multi(const Tile &t, const PassCtx &c, int i, uint32_t *dst, int s0 = 0, int s1 = 9) {
+    const uint32_t kni = t.ckey(c.cur)[i];
+    int count = 0;
+    for (int s = s0; s < s1; ++s) {
+        const uint32_t nk = (uint32_t)((int)kni + (s / 3 - 1) * 65536 + (s % 3 - 1));
+        for (int d = c.live; d >= 0; --d) {
+            const int bd = c.buf(d);
+            const uint32_t m = cell_meta(t, bd, nk);
+            const uint16_t *items = t.hitems(bd);
+            const int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
+            for (int e = 0; e < cn; ++e) {
+                const int j = (int)items[st + e];
+                if (accept_multi(t, c, i, j, s, d, kni)) {
+                    if (FILL) {
+                        dst[count] = (uint32_t)j | ((uint32_t)i << 16);
+                        atomicAdd(&t.done[j], 1u);
+                    }
+                    ++count;
+                }
             }
         }
     }
@@ -612,7 +691,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
 // algorithm, HBM/L2 latency on every access, workgroup-scope release/acquire around the dataflow
 // counters (global memory gives no issue-order guarantee).  Slow, but any island up to the index
 // limits (32766 particles, 60000 visited pairs per pass) is stepped exactly.
-template <bool GLOBAL_LISTS, bool GLOBAL_STATE, bool WIDE = false>
+template <bool GLOBAL_LISTS, bool GLOBAL_STATE, bool WIDE = false, bool MULTIGEN = false>
 __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -635,10 +714,11 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
         t.atx = (double *)carve(p, a * 8);
         t.aty = (double *)carve(p, a * 8);
         t.afd = (double *)carve(p, a * 8);
-        t.ckey_b = (uint32_t *)carve(p, 2 * n * 4);
-        t.cell_b = (uint32_t *)carve(p, 2 * cc * 4);
-        t.hkeys_b = (uint32_t *)carve(p, A.use_grid ? 0 : 2 * cc * 4);
-        t.own_off_b = (uint32_t *)carve(p, (A.single_tile ? 2 : 1) * (n + 1) * 4);
+        const size_t gn = MULTIGEN ? (size_t)max(2, A.gens) : 2;  // hash generations kept (PassCtx)
+        t.ckey_b = (uint32_t *)carve(p, gn * n * 4);
+        t.cell_b = (uint32_t *)carve(p, gn * cc * 4);
+        t.hkeys_b = (uint32_t *)carve(p, A.use_grid ? 0 : gn * cc * 4);
+        t.own_off_b = (uint32_t *)carve(p, (A.single_tile ? gn : 1) * (n + 1) * 4);
         t.inc_off = (uint32_t *)carve(p, (n + 1) * 4);
         t.fill = (uint32_t *)carve(p, n * 4);
         t.done = (uint32_t *)carve(p, n * 4);
@@ -659,12 +739,12 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
         } else {
             t.sc = (int32_t *)carve(p, 16 * 4);
         }
-        t.hitems_b = (uint16_t *)carve(p, 2 * n * 2);
+        t.hitems_b = (uint16_t *)carve(p, gn * n * 2);
         t.pslot = (uint16_t *)carve(p, n * 2);
         t.aslot = (uint16_t *)carve(p, n * 2);
         t.nlo = (uint16_t *)carve(p, n * 2);
         if (!GLOBAL_LISTS) {
-            t.own_ent_b = (uint16_t *)carve(p, A.single_tile ? 2 * l * 2 : 0);
+            t.own_ent_b = (uint16_t *)carve(p, A.single_tile ? gn * l * 2 : 0);
         } else {
             unsigned char *g = GLOBAL_STATE ? p : A.scratch + (size_t)tile * A.scratch_stride;
             t.own_pack = (uint32_t *)g;
@@ -789,9 +869,14 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     }
     __shared__ uint32_t wtot[16];  // per-wave totals of the workgroup-wide prefix sums
 
-    int cur = 0;
-    int have_prev = 0;  // buffers cur^1 hold an un-cleared previous pass
-    int prev_uncut = 1;
+    // Ring of hash-generation buffers (more than 2 only for C == 1, S >= 3).  Which buffer a pass uses and
+    // how many older generations it sees follow from the loop counters alone (the buffer advances once per
+    // sub-step; only the first pass of a sub-step is stale), so no state is carried across the pair
+    // scheduler's loop in registers; the budget-cut history lives in t.sc[10] (bit d: the pass of age d was cut).
+    // The code for more than two generations is compiled into separate kernel variants (MULTIGEN): inlined
+    // into the common ones it cost them their scalar registers (spill reloads inside the scheduler's loop).
+    const int G = MULTIGEN ? max(2, A.gens) : 2;
+    if (tid == 0) t.sc[10] = 0;
     int pass_seq = 0;
     unsigned long long spins_total = 0;
     unsigned int max_list = 0;
@@ -841,9 +926,15 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
 
         for (int c = 0; c < A.n_collision_steps; ++c, ++pass_seq) {
             PassCtx ctx;
+            const int cur = s % G;
+            const int live = (c > 0) ? 0 : (A.n_collision_steps == 1 ? min(s, G - 1) : min(s, 1));
             ctx.cur = cur;
-            ctx.stale = have_prev;
-            ctx.prev_uncut = prev_uncut;
+            ctx.G = G;
+            ctx.prev = (cur + G - 1) % G;
+            ctx.live = live;
+            ctx.stale = live > 0;
+            ctx.cut_mask = 0;  // read from t.sc[10] once the cell grid's barriers have passed
+            ctx.prev_uncut = 1;
 
             // ----------------------------------- rebuild spatial hash, L:1486-1511
             for (int h = tid; h < t.ncell; h += nthreads) t.cell(cur)[h] = 0;
@@ -911,6 +1002,8 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             __syncthreads();
             PROF(2)  // cell hash
 
+            ctx.cut_mask = (unsigned int)t.sc[10];
+            ctx.prev_uncut = !((ctx.cut_mask >> 1) & 1u);
             // ---------------------------------------- visit lists (count, scan, fill)
             // parts == 3: three lanes per particle, one per cell column; the per-column counts are scanned
             // in `sub` (the transposition's scratch, unused until the lists are complete)
@@ -918,9 +1011,12 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             if (parts == 3) {
                 for (int w = tid; w < 3 * n; w += nthreads) {
                     const int i = w / 3, p = w - 3 * i;
-                    sub[w] = ctx.stale ? (uint32_t)enum_stale<false>(t, ctx, i, nullptr, 3 * p, 3 * p + 3)
+                    sub[w] = (MULTIGEN && ctx.live > 1) ? (uint32_t)enum_stale_multi<false>(t, ctx, i, nullptr, 3 * p, 3 * p + 3)
+                             : ctx.stale ? (uint32_t)enum_stale<false>(t, ctx, i, nullptr, 3 * p, 3 * p + 3)
                                        : (uint32_t)enum_fresh_column<false>(t, cur, i, p, nullptr);
                 }
+            } else if (MULTIGEN && ctx.live > 1) {
+                for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_stale_multi<false>(t, ctx, i, nullptr);
             } else if (ctx.stale) {
                 for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_stale<false>(t, ctx, i, nullptr);
             } else {
@@ -950,11 +1046,16 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             } else if (parts == 3) {
                 for (int w = tid; w < 3 * n; w += nthreads) {
                     const int i = w / 3, p = w - 3 * i;
-                    if (ctx.stale)
+                    if (MULTIGEN && ctx.live > 1)
+                        enum_stale_multi<true>(t, ctx, i, &t.own_pack[sub[w]], 3 * p, 3 * p + 3);
+                    else if (ctx.stale)
                         enum_stale<true>(t, ctx, i, &t.own_pack[sub[w]], 3 * p, 3 * p + 3);
                     else
                         enum_fresh_column<true>(t, cur, i, p, &t.own_pack[sub[w]]);
                 }
+            } else if (MULTIGEN && ctx.live > 1) {
+                for (int i = tid; i < n; i += nthreads)
+                    enum_stale_multi<true>(t, ctx, i, &t.own_pack[t.own_off(cur)[i]]);
             } else if (ctx.stale) {
                 for (int i = tid; i < n; i += nthreads)
                     enum_stale<true>(t, ctx, i, &t.own_pack[t.own_off(cur)[i]]);
@@ -1090,14 +1191,10 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             }
 
             // ------------------------------ clear policy between passes, L:1905-1912
-            if (c + 1 < A.n_collision_steps) {
-                have_prev = 0;
-                prev_uncut = 1;
-            } else {
-                have_prev = 1;  // hash lists and collided survive into the next sub-step (Q3)
-                prev_uncut = !this_cut;
-                cur ^= 1;
-            }
+            // (cleared: the next pass is fresh; otherwise the hash lists and collided survive into the next
+            // sub-step (Q3) and, with one pass per sub-step, pile up)
+            if (tid == 0)
+                t.sc[10] = (c + 1 < A.n_collision_steps) ? 0 : (int)(((unsigned int)t.sc[10] << 1) | (this_cut ? 2u : 0u));
         }
 
         // ------------------------------------------------ post-solve, L:1690-1693
@@ -1186,6 +1283,12 @@ egg_step_kernel_wide(EggStepArgs A) {
 }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true, false>(A); }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs(EggStepArgs A) { egg_step_body<true, true>(A); }
+// More than two hash generations alive (one collision pass per sub-step, three or more sub-steps): the same
+// three storage variants with the general list builder compiled in.  A rare configuration; no wide / occupancy
+// tuned instances.
+extern "C" __global__ void __launch_bounds__(256) egg_step_kernel_mg(EggStepArgs A) { egg_step_body<false, false, false, true>(A); }
+extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl_mg(EggStepArgs A) { egg_step_body<true, false, false, true>(A); }
+extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs_mg(EggStepArgs A) { egg_step_body<true, true, false, true>(A); }
 
 #ifdef EGG_PROFILE
 // developer microbenchmark (diagnostic build only): cycles per dependent projection of one wave,

@@ -121,7 +121,8 @@ def test_instance_record_and_last_positions(egg, oracle_mod):
 
 
 def test_unsupported_configuration_fails_loudly(egg):
+    """one collision pass per sub-step keeps a hash generation per sub-step alive; the device path holds 8"""
     h = egg.SimulationHandler()
     h.add(0, 0, 50, 15)
-    with pytest.raises(egg.EggError, match="not implemented on the device path"):
-        h.update(1 / 60, 1 / 60, 3, 1)
+    with pytest.raises(egg.EggError, match="un-cleared hash generations"):
+        h.update(1 / 60, 1 / 60, 9, 1)

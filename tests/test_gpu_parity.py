@@ -90,6 +90,28 @@ def _assert_same_state(h, o):
     assert h.stats()["pair_solves"] == o.total_visited
 
 
+@pytest.mark.parametrize("S,C", [(1, 1), (1, 2), (2, 1), (3, 1), (4, 1), (5, 1), (8, 1), (3, 2), (4, 3)])
+def test_substep_and_pass_variants_vs_oracle(egg, oracle_mod, S, C):
+    """Every (sub-steps, collision passes) shape of the reference's clear policy (L:1905-1912): with ONE pass
+    per sub-step the hash lists and `collided` are never cleared inside a step, so sub-step s sees s
+    generations of cell entries.  Two scenes: a single batch (the budget cuts every yolk pass -> exact-budget
+    tile, `collided` looked up in the cut lists) and nine batches moving through each other."""
+    for xs, ys, moving in ((np.array([400.0]), np.array([300.0]), True), (_grid(9, pitch=120.0) + (True,))):
+        h = egg.SimulationHandler()
+        o = oracle_mod.Oracle()
+        ids = h.add_many(xs, ys, 50, 15)
+        for x, y in zip(xs, ys):
+            o.add(float(x), float(y), 50, 15)
+        for k in range(8):
+            dx, dy = circle_target((0.0, 0.0), 2 * k)
+            h.set_target_positions(ids, xs + dx, ys + dy)
+            for i, x, y in zip(ids, xs, ys):
+                o.set_target_position(int(i), float(x + dx), float(y + dy))
+            h.step(1 / 60, S, C)
+            o.step(1 / 60, S, C)
+        _assert_same_state(h, o)
+
+
 @pytest.mark.parametrize("moving", [False, True])
 def test_config2_256_batches_vs_oracle(egg, oracle_mod, moving):
     xs, ys = _grid(256)

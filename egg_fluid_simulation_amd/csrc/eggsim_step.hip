@@ -34,8 +34,8 @@
 // Diagnostic build only (-DEGG_PROFILE): per-phase cycle sums of tile 0 go to a side buffer that no
 // other code reads.  The shipped library is built without it.
 #ifdef EGG_PROFILE
-__device__ unsigned long long egg_prof[16];
-#define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime(), _pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long egg_prof[32];
+#define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime(), _pacc[24] = {0};
 #define PROF(k)                                                  \
     {                                                            \
         unsigned long long _n = __builtin_amdgcn_s_memtime();   \
@@ -45,6 +45,7 @@ __device__ unsigned long long egg_prof[16];
 #define PROF_FLUSH                                                                                    \
     if (tid == 0 && tile == 0 && n > 64) {                                                          \
         for (int _k = 0; _k < 10; ++_k) atomicAdd(&egg_prof[_k], _pacc[_k]);                           \
+        for (int _k = 10; _k < 24; ++_k) atomicAdd(&egg_prof[_k + 2], _pacc[_k]);                           \
         atomicAdd(&egg_prof[10], rounds_total);                                                      \
         atomicAdd(&egg_prof[11], 1ull);                                                              \
     }
@@ -99,12 +100,16 @@ __device__ inline unsigned char *carve(unsigned char *&p, size_t bytes) {
     return q;
 }
 
-__device__ inline int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+// inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no LDS traffic): log steps
+// inside each row of 16 lanes, then lane 15 of a row is broadcast into the next row (rows 1 and 3), then
+// lane 31 into the upper half.  Lanes that a move does not reach receive 0.
+__device__ inline int wave_incl_scan(int v, int /*lane*/) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -123,8 +128,14 @@ __device__ inline void block_exclusive_scan(const uint32_t *cnt, uint32_t *off, 
     const uint32_t incl = (uint32_t)wave_incl_scan((int)sum, lane);
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    uint32_t run = incl - sum;
-    for (int w = 0; w < wave; ++w) run += wtot[w];
+    // totals of the waves before this one: one load per lane (at most 16 waves), summed along the row
+    const int l16 = lane & 15;
+    int before = (l16 < wave) ? (int)wtot[l16] : 0;
+    before += __builtin_amdgcn_update_dpp(0, before, 0x111, 0xf, 0xf, true);
+    before += __builtin_amdgcn_update_dpp(0, before, 0x112, 0xf, 0xf, true);
+    before += __builtin_amdgcn_update_dpp(0, before, 0x114, 0xf, 0xf, true);
+    before += __builtin_amdgcn_update_dpp(0, before, 0x118, 0xf, 0xf, true);
+    uint32_t run = incl - sum + (uint32_t)__builtin_amdgcn_readlane(before, 15);
     for (int q = b0; q < b1; ++q) {
         const uint32_t v = cnt[q];
         off[q] = PACK ? ((run << 16) | v) : run;
@@ -945,6 +956,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 t.done[i] = 0;
             }
             __syncthreads();
+            PROF(10)  // hash: clear
             for (int i = tid; i < n; i += nthreads) {
                 double2 ps = t.pos[i];
                 double fcx = floor(ps.x / A.cell_size);
@@ -982,9 +994,11 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 if (tid == 0) atomicExch(&A.status->fail_claim, 1);
                 return;
             }
+            PROF(11)  // hash: keys + count
             // cell start offsets: exclusive scan of the per-cell counts, in place (start << 16 | count)
             block_exclusive_scan<true>(t.cell(cur), t.cell(cur), t.ncell, tid, nthreads, wtot);
             __syncthreads();
+            PROF(12)  // hash: cell scan
             // unordered scatter, then rank inside the cell so that each cell's items ascend (L:1509)
             for (int i = tid; i < n; i += nthreads) {
                 uint32_t m = t.cell(cur)[t.pslot[i]];
@@ -992,6 +1006,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 t.inc_tmp[(m >> 16) + pos] = (uint32_t)i;
             }
             __syncthreads();
+            PROF(13)  // hash: scatter
             for (int i = tid; i < n; i += nthreads) {
                 uint32_t m = t.cell(cur)[t.pslot[i]];
                 int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
@@ -1033,6 +1048,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 block_exclusive_scan<false>(t.fill, t.own_off(cur), n, tid, nthreads, wtot);
             }
             __syncthreads();
+            PROF(16)  // list offsets scan
             int total = (int)t.own_off(cur)[n];
             max_list = max(max_list, (unsigned int)total);  // what this pass needs, even when it does not fit
             if (total > t.lcap) {
@@ -1127,6 +1143,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             block_exclusive_scan<false>(t.done, t.inc_off, n, tid, nthreads, wtot);
             for (int i = tid; i < n; i += nthreads) t.fill[i] = 0;
             __syncthreads();
+            PROF(14)  // transpose: scan
             // one lane per visit entry (other | self << 16, as the fill pass left it): append it to the
             // incoming list of `other`
             for (int e = tid; e < total; e += nthreads) {
@@ -1137,6 +1154,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             }
             for (int i = tid; i < n; i += nthreads) t.done[i] = 0;  // from here on: the scheduler's progress counter
             __syncthreads();
+            PROF(15)  // transpose: scatter
             // one lane per incoming entry: its rank in `other`'s pair sequence = incoming pairs from smaller
             // selves, then other's own visits, then incoming pairs from larger selves (stale pass only)
             for (int x = tid; x < total; x += nthreads) {
@@ -1435,7 +1453,7 @@ extern "C" void egg_prof_read(unsigned long long *out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(egg_prof), sizeof(egg_prof));
 }
 extern "C" void egg_prof_reset() {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(egg_prof), z, sizeof(z));
 }
 #endif

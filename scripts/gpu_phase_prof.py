@@ -21,10 +21,13 @@ def run(nb, steps=20):
     L = _ffi.load(); L.egg_prof_reset()
     kms = 0
     for _ in range(steps): h.step(1 / 60, S, Cc); kms += h.stats()["last_step_kernel_ms"]
-    buf = (C.c_ulonglong * 16)(); L.egg_prof_read(buf)
+    buf = (C.c_ulonglong * 32)(); L.egg_prof_read(buf)
     calls = buf[11]
-    tot = sum(buf[k] for k in range(10))
+    tot = sum(buf[k] for k in range(10)) + sum(buf[k] for k in range(12, 26))
     print("S=%d C=%d" % (S, Cc), "batches=%d kernel %.3f ms/step; tile-0 kernels=%d total ticks/kernel=%.0f rounds/kernel=%.0f" % (nb, kms / steps, calls, tot / calls, buf[10] / calls))
+    fine = {12: "hash: clear", 13: "hash: keys+count", 14: "hash: cell scan", 15: "hash: scatter", 16: "transpose: scan", 17: "transpose: scatter", 18: "offsets scan"}
+    for k, nm in fine.items(): print("   %-18s %10.0f ticks/kernel  %5.1f%%" % (nm, buf[k] / calls, 100.0 * buf[k] / tot))
+    print("   (the coarse rows below now exclude the fine rows above: hash = in-cell rank only, transpose = rank pass only, fill = offsets->fill)")
     for k in range(10): print("   %-10s %10.0f ticks/kernel  %5.1f%%" % (names[k], buf[k] / calls, 100.0 * buf[k] / tot))
 if __name__ == "__main__":
     for nb in [int(a) for a in sys.argv[1:]] or [1]: run(nb)

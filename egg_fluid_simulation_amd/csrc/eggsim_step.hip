@@ -366,8 +366,10 @@ struct PassCtx {
 // One column (x offset p - 1) of the 3x3 loop: the visit list of i is the concatenation of its three
 // columns, so three lanes can build it side by side when the workgroup has lanes to spare (wide kernel);
 // otherwise one lane walks the columns in turn (enum_fresh below).
-template <bool FILL>
-__device__ inline int enum_fresh_column(const Tile &t, int cur, int i, int p, uint32_t *dst) {
+// MODE 0: count; 1: fill (write other | self << 16 to dst, count other's incoming pairs); 2: count and keep up
+// to `cap` partners in the 16-bit staging slots at dst, so that the fill needs no second enumeration
+template <int MODE>
+__device__ inline int enum_fresh_column(const Tile &t, int cur, int i, int p, uint32_t *dst, int cap = 0) {
     const uint32_t ki = t.ckey(cur)[i];
     const uint16_t *items = t.hitems(cur);
     uint32_t m[3];
@@ -380,9 +382,11 @@ __device__ inline int enum_fresh_column(const Tile &t, int cur, int i, int p, ui
         for (int e = 0; e < cn; ++e) {
             const int j = items[st + e];
             if (j > i) {
-                if (FILL) {
+                if (MODE == 1) {
                     dst[count] = (uint32_t)j | ((uint32_t)i << 16);
                     atomicAdd(&t.done[j], 1u);
+                } else if (MODE == 2) {
+                    if (count < cap) ((uint16_t *)dst)[count] = (uint16_t)j;
                 }
                 ++count;
             }
@@ -396,7 +400,7 @@ __device__ inline int enum_fresh_column(const Tile &t, int cur, int i, int p, ui
 template <bool FILL>
 __device__ inline int enum_fresh(const Tile &t, int cur, int i, uint32_t *dst) {
     int count = 0;
-    for (int p = 0; p < 3; ++p) count += enum_fresh_column<FILL>(t, cur, i, p, FILL ? dst + count : dst);
+    for (int p = 0; p < 3; ++p) count += enum_fresh_column<FILL ? 1 : 0>(t, cur, i, p, FILL ? dst + count : dst);
     return count;
 }
 
@@ -432,8 +436,8 @@ __device__ inline bool accept_stale(const Tile &t, const PassCtx &c, int i, int 
     return true;
 }
 
-template <bool FILL>
-__device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_t *dst, int s0 = 0, int s1 = 9) {
+template <int MODE>  // as in enum_fresh_column
+__device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_t *dst, int s0 = 0, int s1 = 9, int cap = 0) {
     const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.prev);
     const uint32_t kni = kn[i], koi = ko[i];
     int count = 0;
@@ -458,9 +462,11 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (e0 + q < cn && accept_stale(t, c, i, j[q], s, isnew, kni, koi, knj[q], koj[q])) {
-                        if (FILL) {
+                        if (MODE == 1) {
                             dst[count] = (uint32_t)j[q] | ((uint32_t)i << 16);
                             atomicAdd(&t.done[j[q]], 1u);
+                        } else if (MODE == 2) {
+                            if (count < cap) ((uint16_t *)dst)[count] = (uint16_t)j[q];
                         }
                         ++count;
                     }
@@ -1023,17 +1029,25 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             // parts == 3: three lanes per particle, one per cell column; the per-column counts are scanned
             // in `sub` (the transposition's scratch, unused until the lists are complete)
             uint32_t *sub = t.inc_tmp;
+            // The counting pass keeps what it finds (up to stage_cap partners per lane) in the pair cache's
+            // memory, which is idle until the rank pass: the fill then copies instead of enumerating again.
+            uint16_t *stage = (parts == 3 && t.pinv && !(MULTIGEN && ctx.live > 1)) ? (uint16_t *)t.pinv : nullptr;
+            const int stage_cap = stage ? min(16, (t.lcap * 8) / max(1, 3 * n)) & ~1 : 0;
+            if (stage_cap < 4) stage = nullptr;
             if (parts == 3) {
                 for (int w = tid; w < 3 * n; w += nthreads) {
                     const int i = w / 3, p = w - 3 * i;
+                    uint32_t *slots = stage ? (uint32_t *)(stage + (size_t)w * stage_cap) : nullptr;
                     sub[w] = (MULTIGEN && ctx.live > 1) ? (uint32_t)enum_stale_multi<false>(t, ctx, i, nullptr, 3 * p, 3 * p + 3)
-                             : ctx.stale ? (uint32_t)enum_stale<false>(t, ctx, i, nullptr, 3 * p, 3 * p + 3)
-                                       : (uint32_t)enum_fresh_column<false>(t, cur, i, p, nullptr);
+                             : ctx.stale ? (stage ? (uint32_t)enum_stale<2>(t, ctx, i, slots, 3 * p, 3 * p + 3, stage_cap)
+                                                  : (uint32_t)enum_stale<0>(t, ctx, i, nullptr, 3 * p, 3 * p + 3))
+                                         : (stage ? (uint32_t)enum_fresh_column<2>(t, cur, i, p, slots, stage_cap)
+                                                  : (uint32_t)enum_fresh_column<0>(t, cur, i, p, nullptr));
                 }
             } else if (MULTIGEN && ctx.live > 1) {
                 for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_stale_multi<false>(t, ctx, i, nullptr);
             } else if (ctx.stale) {
-                for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_stale<false>(t, ctx, i, nullptr);
+                for (int i = tid; i < n; i += nthreads) t.fill[i] = (uint32_t)enum_stale<0>(t, ctx, i, nullptr);
             } else {
                 for (int i = tid; i < n; i += nthreads)
                     t.fill[i] = (uint32_t)enum_fresh<false>(t, cur, i, nullptr);
@@ -1062,19 +1076,28 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             } else if (parts == 3) {
                 for (int w = tid; w < 3 * n; w += nthreads) {
                     const int i = w / 3, p = w - 3 * i;
-                    if (MULTIGEN && ctx.live > 1)
-                        enum_stale_multi<true>(t, ctx, i, &t.own_pack[sub[w]], 3 * p, 3 * p + 3);
+                    const uint32_t o = sub[w];
+                    const int cnt = (int)(sub[w + 1] - o);
+                    if (stage && cnt <= stage_cap) {  // staged by the counting pass
+                        const uint16_t *slots = stage + (size_t)w * stage_cap;
+                        for (int q = 0; q < cnt; ++q) {
+                            const uint32_t j = slots[q];
+                            t.own_pack[o + q] = j | ((uint32_t)i << 16);
+                            atomicAdd(&t.done[j], 1u);
+                        }
+                    } else if (MULTIGEN && ctx.live > 1)
+                        enum_stale_multi<true>(t, ctx, i, &t.own_pack[o], 3 * p, 3 * p + 3);
                     else if (ctx.stale)
-                        enum_stale<true>(t, ctx, i, &t.own_pack[sub[w]], 3 * p, 3 * p + 3);
+                        enum_stale<1>(t, ctx, i, &t.own_pack[o], 3 * p, 3 * p + 3);
                     else
-                        enum_fresh_column<true>(t, cur, i, p, &t.own_pack[sub[w]]);
+                        enum_fresh_column<1>(t, cur, i, p, &t.own_pack[o]);
                 }
             } else if (MULTIGEN && ctx.live > 1) {
                 for (int i = tid; i < n; i += nthreads)
                     enum_stale_multi<true>(t, ctx, i, &t.own_pack[t.own_off(cur)[i]]);
             } else if (ctx.stale) {
                 for (int i = tid; i < n; i += nthreads)
-                    enum_stale<true>(t, ctx, i, &t.own_pack[t.own_off(cur)[i]]);
+                    enum_stale<1>(t, ctx, i, &t.own_pack[t.own_off(cur)[i]]);
             } else {
                 for (int i = tid; i < n; i += nthreads)
                     enum_fresh<true>(t, cur, i, &t.own_pack[t.own_off(cur)[i]]);

@@ -66,13 +66,13 @@ __host__ __device__
 #endif
 static inline size_t egg_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-// bytes of one tile's slice of EggStepArgs::scratch (visit lists in global memory)
+// bytes of one tile's slice of EggStepArgs::scratch (visit lists in global memory: own_pack 4 B, inc_tmp 8 B per entry)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 static inline size_t egg_step_scratch_bytes(int lcap, int single_tile, int gens = 2) {
     size_t l = (size_t)lcap, g = (size_t)(gens < 2 ? 2 : gens);
-    return 2 * ((l * 4 + 15) & ~(size_t)15) + ((((single_tile ? g : 0) * l * 2) + 15) & ~(size_t)15);
+    return ((l * 4 + 15) & ~(size_t)15) + ((l * 8 + 15) & ~(size_t)15) + ((((single_tile ? g : 0) * l * 2) + 15) & ~(size_t)15);
 }
 
 // dynamic LDS bytes the step kernel carves for the geometry above (must match eggsim_step.hip)

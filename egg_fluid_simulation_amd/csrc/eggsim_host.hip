@@ -44,7 +44,8 @@ namespace {
 constexpr double kPi = 3.14159265358979323846;
 constexpr size_t kLdsMax = 160 * 1024;  // per CU on gfx950; what a workgroup may use is probed at create
 constexpr int kMaxTileParticles = 32000;  // 15-bit local indices in the kernel's pair sequences
-constexpr int kMaxListEntries = 60000;    // 16-bit round stamps in the DAG executor
+constexpr int kMaxListEntries = 60000;    // lists in LDS: 16-bit list positions in the transposition's records
+constexpr int kMaxGlobalListEntries = 8 << 20;  // lists in global memory (64-bit records): bounded by memory only
 
 std::string g_create_error;
 
@@ -679,7 +680,7 @@ int retile(egg_handle *h, int which) {
             // dense or large tiles: particle state stays in LDS, the visit lists go to global memory
             lc.global_lists = 1;
             lcap = std::max<size_t>({lcap, (size_t)(32.0 * lc.nmax), s.list_min});
-            lcap = std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxListEntries);
+            lcap = std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxGlobalListEntries);
             lc.lcap = (int)lcap;
             lc.lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1, threads, 0, s.gens);
             if (lc.lds > h->lds_limit) want_global_state = true;
@@ -689,7 +690,7 @@ int retile(egg_handle *h, int which) {
             // scratch slice, laid out like the LDS image followed by the lists
             lc.global_lists = lc.global_state = 1;
             lcap = std::max<size_t>({lcap, (size_t)(32.0 * lc.nmax), s.list_min});
-            lc.lcap = (int)std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxListEntries);
+            lc.lcap = (int)std::min<size_t>((lcap + 7) & ~(size_t)7, kMaxGlobalListEntries);
             const size_t state = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 1, threads, 0, s.gens);
             lc.scratch_stride = ((state + 255) & ~(size_t)255) + egg_step_scratch_bytes(lc.lcap, single ? 1 : 0, s.gens) + 256;
             lc.lds = 0;
@@ -983,9 +984,9 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                 // more visited pairs than the launch had list room for: grow and re-run
                 s.list_min = std::max<size_t>(s.list_min, (size_t)(st.max_list * 5 / 4 + 64));
                 s.list_factor *= 1.5;
-                if (s.list_min > (size_t)kMaxListEntries)
+                if (s.list_min > (size_t)kMaxGlobalListEntries)
                     return fail(h, EGG_ERR_UNSUPPORTED, "a tile visits %llu pairs in one pass; limit is %d",
-                                (unsigned long long)st.max_list, kMaxListEntries);
+                                (unsigned long long)st.max_list, kMaxGlobalListEntries);
                 s.tiling_dirty = true;
                 redo = true;
                 continue;

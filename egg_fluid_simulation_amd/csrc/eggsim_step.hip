@@ -75,7 +75,8 @@ struct Tile {
     uint32_t *done;       // [nmax]        pairs finished so far per particle (the dataflow counters)
     uint32_t *own_pack;   // [lcap]        visit lists: other | rank of the pair in other's sequence << 16
                           //               (rank 0 until the rank pass has run)
-    uint32_t *inc_tmp;    // [lcap]        scratch: incoming (self | visit-list position << 16)
+    uint32_t *inc_tmp;    // [lcap]        scratch: incoming (self | visit-list position << 16); with the lists in
+                          //               global memory [lcap] 64-bit entries (self | position << 32): no 16-bit bound
     double2 *pinv;        // [lcap] or null: per visit entry (refined reciprocal of the pair's divisor, its minimum
                           //               distance): the position-independent part of the projection, computed
                           //               by all lanes when the lists are ranked instead of by the serial scheduler
@@ -765,8 +766,8 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
         } else {
             unsigned char *g = GLOBAL_STATE ? p : A.scratch + (size_t)tile * A.scratch_stride;
             t.own_pack = (uint32_t *)g;
-            t.inc_tmp = (uint32_t *)(g + egg_align16(l * 4));
-            t.own_ent_b = (uint16_t *)(g + 2 * egg_align16(l * 4));
+            t.inc_tmp = (uint32_t *)(g + egg_align16(l * 4));  // l 64-bit entries
+            t.own_ent_b = (uint16_t *)(g + egg_align16(l * 4) + egg_align16(l * 8));
         }
         t.s_n = (int)n;
         t.s_c = (int)cc;
@@ -1173,7 +1174,10 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
                 const uint32_t rec = t.own_pack[e];
                 const uint32_t j = rec & 0xFFFFu;
                 const uint32_t pos = atomicAdd(&t.fill[j], 1u);
-                t.inc_tmp[t.inc_off[j] + pos] = (rec >> 16) | ((uint32_t)e << 16);
+                if (GLOBAL_LISTS)
+                    ((unsigned long long *)t.inc_tmp)[t.inc_off[j] + pos] = (unsigned long long)(rec >> 16) | ((unsigned long long)e << 32);
+                else
+                    t.inc_tmp[t.inc_off[j] + pos] = (rec >> 16) | ((uint32_t)e << 16);
             }
             for (int i = tid; i < n; i += nthreads) t.done[i] = 0;  // from here on: the scheduler's progress counter
             __syncthreads();
@@ -1181,12 +1185,23 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             // one lane per incoming entry: its rank in `other`'s pair sequence = incoming pairs from smaller
             // selves, then other's own visits, then incoming pairs from larger selves (stale pass only)
             for (int x = tid; x < total; x += nthreads) {
-                const uint32_t rec = t.inc_tmp[x];
-                const uint32_t cself = rec & 0xFFFFu, e = rec >> 16;
+                uint32_t cself, e;
+                if (GLOBAL_LISTS) {
+                    const unsigned long long rec = ((const unsigned long long *)t.inc_tmp)[x];
+                    cself = (uint32_t)rec & 0xFFFFu;
+                    e = (uint32_t)(rec >> 32);
+                } else {
+                    const uint32_t rec = t.inc_tmp[x];
+                    cself = rec & 0xFFFFu;
+                    e = rec >> 16;
+                }
+                auto inc_self = [&](int q) -> uint32_t {
+                    return GLOBAL_LISTS ? (uint32_t)((const unsigned long long *)t.inc_tmp)[q] & 0xFFFFu : t.inc_tmp[q] & 0xFFFFu;
+                };
                 const int i = (int)(t.own_pack[e] & 0xFFFFu);  // the `other` of entry e: whose incoming list x is in
                 const int st = (int)t.inc_off[i], cn = (int)t.inc_off[i + 1] - st;
                 uint32_t rank = 0;
-                for (int f = 0; f < cn; ++f) rank += ((t.inc_tmp[st + f] & 0xFFFFu) < cself) ? 1u : 0u;
+                for (int f = 0; f < cn; ++f) rank += (inc_self(st + f) < cself) ? 1u : 0u;
                 if (cself > (uint32_t)i) rank += t.own_off(cur)[i + 1] - t.own_off(cur)[i];
                 // bit 15: this pair must take the reference path (position-independent part of the test)
                 const uint32_t slow = pair_needs_reference(t.wr[cself], t.wr[i], A.overlap_factor, A.collision_compliance, eps)
@@ -1202,7 +1217,11 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
             for (int i = tid; i < n; i += nthreads) {
                 const int st = (int)t.inc_off[i], cn = (int)t.inc_off[i + 1] - st;
                 uint32_t nl = 0;
-                for (int f = 0; f < cn; ++f) nl += ((t.inc_tmp[st + f] & 0xFFFFu) < (uint32_t)i) ? 1u : 0u;
+                for (int f = 0; f < cn; ++f) {
+                    const uint32_t sf = GLOBAL_LISTS ? (uint32_t)((const unsigned long long *)t.inc_tmp)[st + f] & 0xFFFFu
+                                                     : t.inc_tmp[st + f] & 0xFFFFu;
+                    nl += (sf < (uint32_t)i) ? 1u : 0u;
+                }
                 t.nlo[i] = (uint16_t)nl;
             }
             __syncthreads();

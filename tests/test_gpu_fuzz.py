@@ -1,0 +1,79 @@
+"""Randomised sessions against the CPU oracle (fixed seeds): batches of different sizes are added and removed
+while the simulation runs, targets drift, jump and collide, configs change live, and the (sub-steps, passes)
+shape changes from step to step.  After every few steps every particle of both types must agree bit for bit
+and the visited-pair counters must match: whatever the tiling, kernel variant or recovery path the host
+picked along the way, the result is the reference's sequential result."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WHITE, YOLK = 0, 1
+
+
+@pytest.fixture(scope="module")
+def egg():
+    import egg_fluid_simulation_amd as e
+    return e
+
+
+def _same(h, o, tag):
+    for w in (WHITE, YOLK):
+        for f in ("x", "y", "vx", "vy"):
+            a, b = h.download(w, f), o.field(w, f)
+            assert a.shape == b.shape and np.array_equal(a, b), (tag, w, f)
+    assert h.stats()["pair_solves"] == o.total_visited, tag
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_random_session_matches_oracle(egg, oracle_mod, seed):
+    from egg_fluid_simulation_amd.default_config import default_configs
+    rng = np.random.default_rng(seed)
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    live = {}  # id -> [x, y, vx, vy] of the target
+
+    def add():
+        x, y = rng.uniform(-300, 900, 2)
+        wr = float(rng.choice([20.0, 35.0, 50.0, 64.0]))
+        yr = float(rng.choice([9.0, 15.0, 20.0]))
+        a = h.add(float(x), float(y), wr, yr)
+        b = o.add(float(x), float(y), wr, yr)
+        assert a == b
+        live[a] = [float(x), float(y), *rng.uniform(-6, 6, 2)]
+
+    for _ in range(int(rng.integers(3, 9))):
+        add()
+    shapes = [(2, 3), (2, 3), (2, 3), (1, 1), (1, 3), (2, 1), (3, 1), (4, 2), (5, 1)]
+    for step in range(100):
+        r = rng.random()
+        if r < 0.10 and len(live) < 14:
+            add()
+        elif r < 0.16 and len(live) > 1:
+            victim = int(rng.choice(sorted(live)))
+            h.remove(victim)
+            o.remove(victim)
+            del live[victim]
+        elif r < 0.20:
+            w, y = default_configs()
+            kw = dict(damping=float(rng.uniform(0.05, 0.6)), collision_strength=float(rng.uniform(0.7, 1.0)),
+                      follow_strength=float(rng.uniform(0.9, 1.0)))
+            w.update(kw)
+            h.set_white_config(w)
+            o.set_config(WHITE, dict(oracle_mod.DEFAULT_WHITE, **kw))
+        for i, t in live.items():
+            if rng.random() < 0.04:  # teleport the target: the blob races after it
+                t[0], t[1] = (float(v) for v in rng.uniform(-300, 900, 2))
+            t[0] += t[2]
+            t[1] += t[3]
+            if rng.random() < 0.1:
+                t[2], t[3] = (float(v) for v in rng.uniform(-6, 6, 2))
+            h.set_target_position(i, t[0], t[1])
+            o.set_target_position(i, t[0], t[1])
+        S, C = shapes[int(rng.integers(len(shapes)))]
+        h.step(1 / 60, S, C)
+        o.step(1 / 60, S, C)
+        if step % 6 == 5:
+            _same(h, o, (seed, step))
+    _same(h, o, (seed, "end"))
+    for i in live:
+        assert h.get_position(i) == o.get_position(i)

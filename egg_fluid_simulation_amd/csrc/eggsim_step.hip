@@ -708,7 +708,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
 // A.scratch.  This is the fallback for islands whose particle state does not fit into LDS: same
 // algorithm, HBM/L2 latency on every access, workgroup-scope release/acquire around the dataflow
 // counters (global memory gives no issue-order guarantee).  Slow, but any island up to the index
-// limits (32766 particles, 60000 visited pairs per pass) is stepped exactly.
+// limit (32766 particles) is stepped exactly.
 template <bool GLOBAL_LISTS, bool GLOBAL_STATE, bool WIDE = false, bool MULTIGEN = false>
 __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
     extern __shared__ __align__(16) unsigned char smem[];

@@ -178,7 +178,7 @@ def test_result_is_independent_of_tiling(egg):
 def test_large_island_falls_back_to_global_memory_state(egg, oracle_mod):
     """4 x 4 batches at 95 px pitch overlap into ONE island of 2512 white particles, far beyond what
     fits in LDS.  The step kernel then keeps the tile's state in global memory; results stay exact.
-    (Index limits remain: 32766 particles and 60000 visited pairs per pass in one island.)"""
+    (Index limit: 32766 particles of one type in one island.)"""
     k = np.arange(16)
     xs, ys = 500.0 + 95.0 * (k % 4), 500.0 + 95.0 * (k // 4)
     h, o, _ = _run_both(egg, oracle_mod, xs, ys, 3, False)

@@ -119,10 +119,11 @@ def main():
         if halo is None:
             h.step(1 / 60, 2, 3)
             return
-        # neighbours' boundary-batch claims travel while the step kernels run; a conflict (a batch
-        # about to cross a cut) raises -- the tiled benchmark never produces one
-        halo.post()
+        # the kernels are launched first; the claims of this step (fixed by step_begin's tiling) are collected,
+        # sent to the neighbours and checked while they run; a conflict (a batch about to cross a cut)
+        # raises -- the tiled benchmark never produces one
         h.step_begin(1 / 60, 2, 3)
+        halo.post(claims_fixed=True)
         halo.finish()
         h.step_end(True)
 

@@ -85,6 +85,7 @@ class BoundaryExchange:
         self.halo_px, self.interact_px, self.capacity = float(halo_px), tuple(float(v) for v in interact_px), int(capacity)
         self.dist = group
         self.bounds_fn = bounds_fn or self._handler_bounds
+        self.claims_fixed = False
         self.ghosts = {}          # neighbour rank -> (ids, boxes) received in the last exchange
         self.sent = {}            # neighbour rank -> number of boxes sent
         self.bytes_exchanged = 0
@@ -107,7 +108,8 @@ class BoundaryExchange:
         return [r for r in (self.rank - 1, self.rank + 1) if 0 <= r < self.world]
 
     def _handler_bounds(self):
-        self.handler.prepare_step()
+        if not self.claims_fixed:  # a step already launched (step_begin) has fixed this step's claims
+            self.handler.prepare_step()
         ids = np.asarray(self.handler.list_ids(), dtype=np.int64)
         boxes, cells = self.handler.get_claims(ids)
         self.interact_px = cells
@@ -145,10 +147,13 @@ class BoundaryExchange:
         li, gi = np.nonzero(near.T)[::-1]
         return [(int(ids[a]), int(ghost_ids[b_])) for a, b_ in zip(li, gi)]
 
-    def post(self):
-        """First half of the exchange: collect this rank's claims and start the sends / receives."""
+    def post(self, claims_fixed=False):
+        """First half of the exchange: collect this rank's claims and start the sends / receives.
+        claims_fixed: the step was already launched with step_begin (its tiling fixed the claims), so the
+        host work of the exchange runs while the kernels do."""
         if self.world == 1:
             return
+        self.claims_fixed = claims_fixed
         torch, dist = self.torch, self.dist
         ids, boxes = self.bounds_fn()
         ids = np.asarray(ids, dtype=np.int64)
@@ -275,8 +280,8 @@ class ShardedSimulationHandler:
         if self.world == 1:
             self.local.step(delta, n_substeps, n_collision_steps)
             return 0
-        self.exchange.post()
-        self.local.step_begin(delta, n_substeps, n_collision_steps)
+        self.local.step_begin(delta, n_substeps, n_collision_steps)  # fixes this step's claims, launches the kernels
+        self.exchange.post(claims_fixed=True)
         conflicts = self.exchange.finish(raise_on_conflict=False)
         # strays (batches deep inside another slab) are balanced too, but never force a re-run by themselves.
         # The second flag guards the collision budget (simulation_handler.lua:1657-1658): the reference
@@ -328,7 +333,8 @@ class ShardedSimulationHandler:
 
     # ------------------------------------------------------------ internals
     def _bounds(self):
-        self.local.prepare_step(*self._step_args)
+        if not self.exchange.claims_fixed:
+            self.local.prepare_step(*self._step_args)
         gids = np.array(sorted(self.local_id), dtype=np.int64)
         if len(gids) == 0:
             return gids, np.zeros((0, 8))

@@ -49,6 +49,6 @@ def test_overlapping_batches_negative_coordinates(oracle_mod):
     _run(oracle_mod, [(0, 0), (30, 10), (-20, 40)], 4)
 
 
-@pytest.mark.parametrize("S,C", [(1, 2), (2, 1), (3, 2)])
+@pytest.mark.parametrize("S,C", [(1, 2), (2, 1), (3, 2), (3, 1), (5, 1)])
 def test_substep_and_pass_variants(oracle_mod, S, C):
     _run(oracle_mod, [(10, 10), (60, 10)], 3, S, C)

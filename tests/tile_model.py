@@ -31,37 +31,32 @@ def slot_of(dcx, dcy):
     return -1
 
 
-def build_visit_lists(n, newc, oldc, prev_own):
+def build_visit_lists(n, newc, older):
     """(A): own[i] = ordered list of partners particle i visits as `self`.
 
-    newc[i] = (cx, cy) of this pass; oldc = cells of the previous un-cleared pass
-    or None; prev_own = that pass's (cut) visit lists or None.
+    newc[i] = (cx, cy) of this pass; older = [(cells, own), ...], oldest first: the cells and the
+    (cut) visit lists of every earlier pass whose hash entries and `collided` marks were not cleared
+    (one such pass after a sub-step boundary, L:1905-1912; with a single collision pass per sub-step
+    nothing is ever cleared inside a step, so every earlier sub-step of the step is in there).
     """
-    stale = oldc is not None
-    cells_new = {}
-    for i in range(n):
-        cells_new.setdefault(newc[i], []).append(i)
-    cells_old = {}
-    if stale:
+    gens = [c for c, _ in older] + [newc]  # a cell's list holds the oldest generation's entries first
+    cells = []
+    for g in gens:
+        d = {}
         for i in range(n):
-            cells_old.setdefault(oldc[i], []).append(i)
+            d.setdefault(g[i], []).append(i)
+        cells.append(d)
 
-    def in_prev(a, b):
-        lo, hi = (a, b) if a < b else (b, a)
-        return prev_own is not None and (hi in prev_own[lo] or lo in prev_own[hi])
+    def in_collided(a, b):
+        return any(b in own[a] or a in own[b] for _, own in older)
 
     def cand_key(i, j):
         """first-occurrence key of j in i's attempt order, or None if j is not met"""
         best = None
-        if stale:
-            s = slot_of(oldc[j][0] - newc[i][0], oldc[j][1] - newc[i][1])
-            if s >= 0:
-                best = (s, 0, j)
-        s = slot_of(newc[j][0] - newc[i][0], newc[j][1] - newc[i][1])
-        if s >= 0:
-            k = (s, 1, j)
-            if best is None or k < best:
-                best = k
+        for gi, g in enumerate(gens):
+            s = slot_of(g[j][0] - newc[i][0], g[j][1] - newc[i][1])
+            if s >= 0 and (best is None or (s, gi, j) < best):
+                best = (s, gi, j)
         return best
 
     own = []
@@ -72,15 +67,16 @@ def build_visit_lists(n, newc, oldc, prev_own):
         for ox in (-1, 0, 1):
             for oy in (-1, 0, 1):
                 cell = (cx + ox, cy + oy)
-                for j in cells_old.get(cell, []) + cells_new.get(cell, []):
-                    if j == i or j in seen:
-                        continue
-                    seen.add(j)
-                    if in_prev(i, j):
-                        continue
-                    if j < i and cand_key(j, i) is not None:
-                        continue  # j's loop met i first
-                    lst.append(cand_key(i, j))
+                for d in cells:
+                    for j in d.get(cell, []):
+                        if j == i or j in seen:
+                            continue
+                        seen.add(j)
+                        if in_collided(i, j):
+                            continue
+                        if j < i and cand_key(j, i) is not None:
+                            continue  # j's loop met i first
+                        lst.append(cand_key(i, j))
         lst.sort()
         own.append([k[2] for k in lst])
     return own
@@ -220,7 +216,7 @@ class TileModel:
         cell = max(1, cfg["max_radius"] * max(cfg["collision_overlap_factor"],
                                               cfg["cohesion_interaction_distance_factor"]))
         x, y, w = st["x"], st["y"], st["w"]
-        oldc, prev_own = None, None
+        older = []  # (cells, visit lists) of the passes not cleared since
         self.log = []
         for s in range(S):
             px, py = list(x), list(y)
@@ -241,14 +237,14 @@ class TileModel:
                     y[i] = y[i] + ny * lam * w[i]
             for c in range(C):
                 newc = [(math.floor(x[i] / cell), math.floor(y[i] / cell)) for i in range(n)]
-                own = build_visit_lists(n, newc, oldc, prev_own)
+                own = build_visit_lists(n, newc, older)
                 own, was_cut = cut_at_budget(own, w, budget)
                 rounds = execute_dag(st, own, cfg["collision_overlap_factor"], cc)
                 self.log.append((sum(len(l) for l in own), int(was_cut), rounds))
                 if c + 1 < C:
-                    oldc, prev_own = None, None  # cleared (L:1905-1912)
+                    older = []  # cleared (L:1905-1912)
                 else:
-                    oldc, prev_own = newc, own   # survives into the next sub-step (Q3)
+                    older.append((newc, own))  # survives into the next sub-step (Q3), on top of what it saw
             for i in range(n):
                 self.vx[i] = (x[i] - px[i]) / sub
                 self.vy[i] = (y[i] - py[i]) / sub

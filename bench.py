@@ -38,11 +38,20 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 PITCH = 160.0                         # px between batch centres (BASELINE config 2: islands never touch)
 
 
-def grid_positions(n_batches, column_offset=0):
-    side = int(math.ceil(math.sqrt(n_batches)))
-    k = np.arange(n_batches)
-    xs = 100.0 + PITCH * (k % side + column_offset * side)
-    ys = 100.0 + PITCH * (k // side)
+def site_pitch(overlap=1):
+    """k coincident blobs spread to ~sqrt(k) times the radius: keep the sites' islands apart"""
+    return PITCH * (1.0 if overlap <= 1 else 1.25 * math.ceil(math.sqrt(overlap)))
+
+
+def grid_positions(n_batches, column_offset=0, overlap=1):
+    """batch centres on a PITCH grid; overlap > 1 puts that many consecutive batches on the same centre
+    (BASELINE config 3: forced spatial overlap)"""
+    n_sites = (n_batches + overlap - 1) // overlap
+    side = int(math.ceil(math.sqrt(n_sites)))
+    k = np.arange(n_batches) // overlap
+    pitch = site_pitch(overlap)
+    xs = 100.0 + pitch * (k % side + column_offset * side)
+    ys = 100.0 + pitch * (k // side)
     return xs.astype(np.float64), ys.astype(np.float64), side
 
 
@@ -80,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batches", type=int, default=256, help="batches per GPU (256 = BASELINE config 2)")
     ap.add_argument("--tile-target", type=int, default=0, help="pack independent islands into tiles of this size")
+    ap.add_argument("--overlap", type=int, default=1, help="coincident batches per site (4 = BASELINE config 3; not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,11 +119,12 @@ def main():
     h = SimulationHandler(device=local_rank)  # raises without a GPU: no CPU path
     if args.tile_target:
         h.set_option(_ffi.OPT_TILE_TARGET_PARTICLES, args.tile_target)
-    xs, ys, side = grid_positions(args.batches, column_offset=rank)
+    xs, ys, side = grid_positions(args.batches, column_offset=rank, overlap=args.overlap)
     ids = h.add_many(xs, ys, 50, 15)
     n_white, n_yolk = h.get_n_particles()
-    halo = BoundaryExchange(h, rank, world, slab_lo=100.0 + PITCH * rank * side - PITCH / 2,
-                            slab_hi=100.0 + PITCH * (rank + 1) * side - PITCH / 2, group=dist) if world > 1 else None
+    pitch = site_pitch(args.overlap)
+    halo = BoundaryExchange(h, rank, world, slab_lo=100.0 + pitch * rank * side - pitch / 2,
+                            slab_hi=100.0 + pitch * (rank + 1) * side - pitch / 2, group=dist) if world > 1 else None
 
     def one_step():
         if halo is None:
@@ -181,9 +192,10 @@ def main():
             "steps_per_sec": steps_per_sec,
             "constraint_solves_per_sec": (pairs + follows) / elapsed,
             "particles": int(total_particles),
-            "config": {"workload": "BASELINE config 2: %d non-overlapping batches per GPU (white r=50, yolk r=15) on a "
-                                   "%.0f px grid, default config, dt=1/60, 2 sub-steps x 3 collision passes"
-                                   % (args.batches, PITCH),
+            "config": {"workload": ("BASELINE config 2: %d non-overlapping batches per GPU" % args.batches if args.overlap == 1 else
+                                    "BASELINE config 3 layout: %d batches per GPU, %d coincident per site" % (args.batches, args.overlap)) +
+                                   " (white r=50, yolk r=15) on a %.0f px grid, default config, dt=1/60, 2 sub-steps x 3 "
+                                   "collision passes" % site_pitch(args.overlap),
                        "batches_per_gpu": args.batches, "particles_per_gpu": int(n_white + n_yolk),
                        "parallelism": "slab%d" % world, "tiles": s1["n_tiles"], "retiles": s1["retiles"] - s0["retiles"],
                        "redo_steps": s1["redo_steps"] - s0["redo_steps"]},

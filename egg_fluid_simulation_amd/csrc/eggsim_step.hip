@@ -1325,7 +1325,9 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
 }  // namespace
 
 // tiles of up to 256 particles (the common case): 4 waves, up to 512 registers per lane, no spills
-extern "C" __global__ void __launch_bounds__(256) egg_step_kernel(EggStepArgs A) { egg_step_body<false, false>(A); }
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) egg_step_kernel(EggStepArgs A) {
+    egg_step_body<false, false>(A);
+}
 // the same with registers capped at 96 (5 waves per SIMD): when thousands of tiles queue for the
 // chip, six resident tiles per CU beat the spill-free build's four (measured: 2.75 -> 2.15 ms per
 // step at 4096 batches), while a tile that has its CU to itself is ~3 % slower

@@ -27,8 +27,6 @@
 #include "eggsim_device.h"
 
 #define EGG_EMPTY_KEY 0xFFFFFFFFu
-#define EGG_NONE 0xFFFFu
-#define EGG_SELF 0x8000u
 #define EGG_IDX 0x7FFFu
 
 // Diagnostic build only (-DEGG_PROFILE): per-phase cycle sums of tile 0 go to a side buffer that no

@@ -52,6 +52,14 @@ class EggBatchInfo(C.Structure):
                 ("yolk_radius", C.c_double), ("n_white", C.c_int64), ("n_yolk", C.c_int64)]
 
 
+ENVIRONMENT_FIELDS = ("min_x", "min_y", "max_x", "max_y", "centroid_x", "centroid_y", "max_radius", "max_velocity",
+                      "last_centroid_x", "last_centroid_y")
+
+
+class EggEnvironment(C.Structure):  # egg_environment
+    _fields_ = [(k, C.c_double) for k in ENVIRONMENT_FIELDS]
+
+
 class EggStats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("pair_solves", C.c_int64), ("follow_solves", C.c_int64),
                 ("kernel_launches", C.c_int64), ("retiles", C.c_int64), ("redo_steps", C.c_int64),
@@ -97,6 +105,7 @@ _SIGNATURES = {
     "egg_download_particles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "egg_selftest_arith": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]),
     "egg_get_stats": (C.c_int, [C.c_void_p, C.POINTER(EggStats)]),
+    "egg_get_environment": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(EggEnvironment)]),
     "egg_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
 }
 

@@ -26,6 +26,9 @@ extern "C" __global__ void egg_step_kernel(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_occ(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_wide(EggStepArgs A);
+extern "C" __global__ void egg_env_bounds_kernel(const double *, const double *, const double *, const double *, const double *, int,
+                                                   unsigned long long *);
+extern "C" __global__ void egg_env_sums_kernel(const double *, const double *, const double *, const double *, int, double *);
 extern "C" __global__ void egg_step_kernel_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gs_mg(EggStepArgs A);
@@ -152,6 +155,7 @@ struct System {  // one particle type
     bool disp_valid = false;                    // fetched together with the boxes of the current positions
     bool swept = false;                          // some claim was extended along predicted motion
     std::vector<int> extra_margin;               // per batch: extra claim cells after a failed check (decays)
+    DevBuf<unsigned long long> d_env;            // egg_get_environment: 6 ordered keys + 4 sums
     DevBuf<int32_t> d_atom_fail;                 // per atom: a particle left the claim in the last launch
     // tiles
     std::vector<int32_t> tile_atom_begin, tile_atoms;
@@ -1815,6 +1819,55 @@ int egg_selftest_arith(egg_handle *h, int64_t n_operand_pairs, uint64_t seed, in
     HIP_TRY(h, hipMemcpyAsync(&bad, d.p, sizeof bad, hipMemcpyDeviceToHost, h->sys[0].stream));
     HIP_TRY(h, hipStreamSynchronize(h->sys[0].stream));
     *mismatches = (int64_t)bad;
+    return EGG_OK;
+}
+
+int egg_get_environment(egg_handle *h, int which, egg_environment *out) {
+    if (!h || !out || which < 0 || which > 1) return EGG_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    System &s = h->sys[which];
+    const double inf = std::numeric_limits<double>::infinity();
+    *out = egg_environment{inf, inf, -inf, -inf, 0, 0, 0, 0, 0, 0};  // L:1358-1390
+    if (h->stats.steps == 0 || s.n == 0) return EGG_OK;
+    auto key = [](double d) {
+        unsigned long long u;
+        memcpy(&u, &d, 8);
+        return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    };
+    auto unkey = [](unsigned long long k) {
+        unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+        double d;
+        memcpy(&d, &u, 8);
+        return d;
+    };
+    // scratch: 6 ordered keys + 4 sums, in the type's scratch-free status staging area would alias live data,
+    // so a small dedicated buffer
+    HIP_TRY(h, s.d_env.reserve(16, false, s.stream));
+    unsigned long long init[6] = {key(inf), key(inf), key(-inf), key(-inf), key(0.0), key(0.0)};
+    HIP_TRY(h, hipMemcpyAsync(s.d_env.p, init, sizeof init, hipMemcpyHostToDevice, s.stream));
+    const int n = (int)s.n;
+    const int blocks = std::min(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(egg_env_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, s.stream, s.x[s.cur].p, s.y[s.cur].p,
+                       s.vx[s.cur].p, s.vy[s.cur].p, s.radius.p, n, s.d_env.p);
+    hipLaunchKernelGGL(egg_env_sums_kernel, dim3(4), dim3(EGG_WAVE), 0, s.stream, s.x[s.cur].p, s.y[s.cur].p,
+                       s.x[s.cur ^ 1].p, s.y[s.cur ^ 1].p, n, (double *)(s.d_env.p + 6));
+    HIP_TRY(h, hipGetLastError());
+    h->stats.kernel_launches += 2;
+    unsigned long long back[10];
+    HIP_TRY(h, hipMemcpyAsync(back, s.d_env.p, sizeof back, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(h, hipStreamSynchronize(s.stream));
+    double sums[4];
+    memcpy(sums, back + 6, sizeof sums);
+    out->min_x = unkey(back[0]);
+    out->min_y = unkey(back[1]);
+    out->max_x = unkey(back[2]);
+    out->max_y = unkey(back[3]);
+    out->max_radius = unkey(back[4]);
+    out->max_velocity = unkey(back[5]);
+    out->centroid_x = sums[0] / (double)n;
+    out->centroid_y = sums[1] / (double)n;
+    out->last_centroid_x = sums[2] / (double)n;
+    out->last_centroid_y = sums[3] / (double)n;
     return EGG_OK;
 }
 

@@ -1591,6 +1591,74 @@ extern "C" __global__ void egg_rederive_kernel(const double *mass_t, double *inv
     if (do_radius) radius[i] = min_radius * (1 - tt) + max_radius * tt;
 }
 
+// ---------------------------------------------------------------------------
+// The per-type reductions the reference keeps in its environment for :draw() (L:1669-1718, L:1795-1815).
+
+// order-preserving map double -> unsigned (so that atomicMin / atomicMax work on doubles)
+__device__ inline unsigned long long egg_ordered_key(double d) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// keys[0..5] = min(x - r), min(y - r), max(x + r), max(y + r), max r, max |v| as ordered keys, initialised by
+// the host to +inf, +inf, -inf, -inf, 0, 0 (the reference's start values, L:1670-1675).  min / max are exact
+// whatever the order; NaN never wins a comparison in the reference and is skipped here.
+extern "C" __global__ void egg_env_bounds_kernel(const double *x, const double *y, const double *vx, const double *vy,
+                                                   const double *radius, int n, unsigned long long *keys) {
+    double lo_x = __longlong_as_double(0x7FF0000000000000ll), lo_y = lo_x, hi_x = -lo_x, hi_y = -lo_x, mr = 0.0, mv = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double px = x[i], py = y[i], r = radius[i], ux = vx[i], uy = vy[i];
+        const double a = px - r, b = py - r, c = px + r, d = py + r;
+        const double m = sqrt(ux * ux + uy * uy);  // math.magnitude, math.lua:96-98
+        if (a < lo_x) lo_x = a;
+        if (b < lo_y) lo_y = b;
+        if (c > hi_x) hi_x = c;
+        if (d > hi_y) hi_y = d;
+        if (r > mr) mr = r;
+        if (m > mv) mv = m;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        lo_x = fmin(lo_x, __shfl_xor(lo_x, s, 64));
+        lo_y = fmin(lo_y, __shfl_xor(lo_y, s, 64));
+        hi_x = fmax(hi_x, __shfl_xor(hi_x, s, 64));
+        hi_y = fmax(hi_y, __shfl_xor(hi_y, s, 64));
+        mr = fmax(mr, __shfl_xor(mr, s, 64));
+        mv = fmax(mv, __shfl_xor(mv, s, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&keys[0], egg_ordered_key(lo_x));
+        atomicMin(&keys[1], egg_ordered_key(lo_y));
+        atomicMax(&keys[2], egg_ordered_key(hi_x));
+        atomicMax(&keys[3], egg_ordered_key(hi_y));
+        atomicMax(&keys[4], egg_ordered_key(mr));
+        atomicMax(&keys[5], egg_ordered_key(mv));
+    }
+}
+
+// Block b adds up array b (x, y, last_x, last_y) in particle order, like the reference's loops (L:1700-1701,
+// L:1803-1804): floating-point addition does not associate, so the sum is serial; the wave only stages 64
+// values at a time (one coalesced load) and every lane adds them in order.  out[b] = the sum.
+extern "C" __global__ void egg_env_sums_kernel(const double *a0, const double *a1, const double *a2, const double *a3, int n,
+                                                 double *out) {
+    const double *a = blockIdx.x == 0 ? a0 : blockIdx.x == 1 ? a1 : blockIdx.x == 2 ? a2 : a3;
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    double v = (lane < n) ? a[lane] : 0.0;
+    for (int base = 0; base < n; base += 64) {
+        const double cur = v;
+        const int nxt = base + 64 + lane;
+        v = (nxt < n) ? a[nxt] : 0.0;  // next chunk travels while this one is added
+        const int m = min(64, n - base);
+        const int lo = (int)(__double_as_longlong(cur) & 0xFFFFFFFFll), hi = (int)(__double_as_longlong(cur) >> 32);
+        for (int k = 0; k < m; ++k) {
+            const unsigned int l = (unsigned int)__builtin_amdgcn_readlane(lo, k), u = (unsigned int)__builtin_amdgcn_readlane(hi, k);
+            s = s + __longlong_as_double((long long)(((unsigned long long)u << 32) | l));
+        }
+    }
+    if (lane == 0) out[blockIdx.x] = s;
+}
+
 // get_position (L:281-295, L:1134-1148): sequential sum over the batch's white then yolk
 // particles, in index order, then one division -- one thread per requested batch so the
 // floating-point summation order is the reference's.

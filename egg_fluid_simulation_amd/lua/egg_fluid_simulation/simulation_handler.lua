@@ -39,6 +39,9 @@ int egg_get_position(egg_handle *h, int64_t id, double *x, double *y);
 int egg_get_n_particles(const egg_handle *h, int64_t id, int64_t *n_white, int64_t *n_yolk);
 int egg_list_ids(const egg_handle *h, int64_t cap, int64_t *ids, int64_t *n);
 int egg_download_particles(egg_handle *h, int which, int field, double *dst, int64_t cap);
+typedef struct { double min_x, min_y, max_x, max_y, centroid_x, centroid_y, max_radius, max_velocity,
+                 last_centroid_x, last_centroid_y; } egg_environment;
+int egg_get_environment(egg_handle *h, int which, egg_environment *out);
 ]]
 
 local lib = ffi.load(os.getenv("EGGSIM_LIB") or "eggsim")
@@ -225,8 +228,21 @@ function SimulationHandler:get_instance_data(white_or_yolk)
     return out, n
 end
 
+--- the fields the reference's environments hold for :draw(): particle AABB incl. radius, centroid, largest
+--- radius / speed, centroid at the start of the last step (simulation_handler.lua:1669-1718, 1795-1815,
+--- used at 1946-1950, 2007, 2132 to size and place the canvases)
+function SimulationHandler:get_environment(white_or_yolk)
+    local e = ffi.new("egg_environment[1]")
+    self:_check(lib.egg_get_environment(self._h, white_or_yolk and 0 or 1, e))
+    local v = e[0]
+    return { min_x = v.min_x, min_y = v.min_y, max_x = v.max_x, max_y = v.max_y, centroid_x = v.centroid_x,
+             centroid_y = v.centroid_y, max_radius = v.max_radius, max_velocity = v.max_velocity,
+             last_centroid_x = v.last_centroid_x, last_centroid_y = v.last_centroid_y }
+end
+
 function SimulationHandler:draw()
-    -- rendering is outside the device path; feed :get_instance_data() to the reference's shaders
+    -- rendering is outside the device path; feed :get_instance_data() and :get_environment() to the reference's
+    -- shaders and canvas code
 end
 
 return SimulationHandler

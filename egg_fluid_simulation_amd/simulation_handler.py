@@ -429,6 +429,13 @@ class SimulationHandler:
         cols = [self.download(which, f) for f in ("x", "y", "last_x", "last_y", "vx", "vy", "radius")]
         return np.stack(cols, axis=1) if cols[0].size else np.zeros((0, 7))
 
+    def get_environment(self, which):
+        """the reductions the reference keeps per particle type for :draw() -- AABB incl. radius, centroid, largest
+        radius and speed, centroid at the start of the last step (simulation_handler.lua:1669-1718, 1795-1815)"""
+        e = _ffi.EggEnvironment()
+        self._check(self._lib.egg_get_environment(self._h, int(which), C.byref(e)))
+        return {k: getattr(e, k) for k in _ffi.ENVIRONMENT_FIELDS}
+
     def stats(self):
         s = _ffi.EggStats()
         self._check(self._lib.egg_get_stats(self._h, C.byref(s)))

@@ -168,6 +168,20 @@ enum {
  * record (L:513-517, L:744-813). */
 int egg_download_particles(egg_handle *h, int which, int field, double *dst, int64_t cap);
 
+/* The per-type reductions the reference's _post_solve / update_last_positions keep in its environment
+ * (L:1669-1718, L:1795-1815) -- what :draw() sizes and places its canvases with (L:1946-1950, L:2007,
+ * L:2132).  Computed on demand from the device arrays, bounds and maxima in parallel, the centroid sums
+ * serially in particle order like the reference: after every _step they equal the reference's env fields
+ * bit for bit.  (The reference's fields stay stale until the next _step when batches are added or removed
+ * in between; these follow the arrays.)  Before the first _step: bounds +-inf, everything else 0. */
+typedef struct {
+    double min_x, min_y, max_x, max_y;        /* AABB including the particle radius */
+    double centroid_x, centroid_y;            /* mean position */
+    double max_radius, max_velocity;
+    double last_centroid_x, last_centroid_y;  /* mean of the positions at the start of the most recent _step */
+} egg_environment;
+int egg_get_environment(egg_handle *h, int which, egg_environment *out);
+
 /* counters of the device path, cumulative since creation */
 typedef struct {
     int64_t steps;           /* _step calls executed */

@@ -120,6 +120,30 @@ def test_instance_record_and_last_positions(egg, oracle_mod):
         assert np.array_equal(rec[:, col], o.field(WHITE, f)), f
 
 
+def test_environment_reductions_match_the_reference_fields(egg, oracle_mod):
+    """what :draw() sizes and places its canvases with: AABB incl. radius, centroids (summed in particle order),
+    largest radius and speed -- bit for bit the fields the reference's env holds after each step"""
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    for w in (WHITE, YOLK):
+        e = h.get_environment(w)
+        assert e["min_x"] == float("inf") and e["max_y"] == -float("inf") and e["centroid_x"] == 0.0
+    cs = [(-30.0, 12.0), (400.0, 300.0), (415.0, 310.0), (900.0, -250.0)]
+    for k, (x, y) in enumerate(cs):
+        h.add(x, y, 50 if k % 2 == 0 else 35, 15)
+        o.add(x, y, 50 if k % 2 == 0 else 35, 15)
+    for step in range(12):
+        for i, (x, y) in enumerate(cs):
+            h.set_target_position(i + 1, x + 3.0 * step, y - 2.0 * step)
+            o.set_target_position(i + 1, x + 3.0 * step, y - 2.0 * step)
+        h.update(1 / 60)
+        o.update(1 / 60)
+        if step in (0, 5, 11):
+            for w in (WHITE, YOLK):
+                mine, ref = h.get_environment(w), o.env(w)
+                for key in mine:
+                    assert mine[key] == ref[key], (step, w, key, mine[key], ref[key])
+
+
 def test_unsupported_configuration_fails_loudly(egg):
     """one collision pass per sub-step keeps a hash generation per sub-step alive; the device path holds 8"""
     h = egg.SimulationHandler()

@@ -871,7 +871,7 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev1, s.stream));
     // one copy brings back the status blocks and, behind them, the atoms' end-of-step cell boxes and
     // last-sub-step travel: the next tiling (every step while targets move) then needs no further round trip
-    const bool with_boxes = na && na <= 65536;
+    const bool with_boxes = na && na <= (size_t)4 << 20;  // 32 B per atom; beyond that the boxes are fetched when a tiling needs them
     const size_t bytes = (2 * kStatInts + (with_boxes ? 8 * na : 0)) * sizeof(int32_t);
     HIP_TRY(h, s.stage_down.reserve(bytes));
     HIP_TRY(h, hipMemcpyAsync(s.stage_down.p, s.d_out.p, bytes, hipMemcpyDeviceToHost, s.stream));

@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--batches", type=int, default=256, help="batches per GPU (256 = BASELINE config 2)")
     ap.add_argument("--tile-target", type=int, default=0, help="pack independent islands into tiles of this size")
     ap.add_argument("--overlap", type=int, default=1, help="coincident batches per site (4 = BASELINE config 3; not the headline config)")
+    ap.add_argument("--no-fuse", action="store_true", help="one launch per particle type even on a full chip (A/B testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,6 +120,8 @@ def main():
     h = SimulationHandler(device=local_rank)  # raises without a GPU: no CPU path
     if args.tile_target:
         h.set_option(_ffi.OPT_TILE_TARGET_PARTICLES, args.tile_target)
+    if args.no_fuse:
+        h.set_option(_ffi.OPT_FUSE_TYPES, 0)
     xs, ys, side = grid_positions(args.batches, column_offset=rank, overlap=args.overlap)
     ids = h.add_many(xs, ys, 50, 15)
     n_white, n_yolk = h.get_n_particles()

@@ -36,6 +36,7 @@ OPT_SPIN_SLEEP = 5
 OPT_BUDGET_PARTICLES_WHITE = 6
 OPT_BUDGET_PARTICLES_YOLK = 7
 OPT_FORCE_GLOBAL_STATE = 8
+OPT_FUSE_TYPES = 9
 
 CONFIG_FIELDS = ["damping", "follow_strength", "cohesion_strength",
                  "cohesion_interaction_distance_factor", "collision_strength",

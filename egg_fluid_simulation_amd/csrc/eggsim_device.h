@@ -53,6 +53,7 @@ struct EggStepArgs {
     int32_t use_grid;  // 1: cells are a dense grid over the tile's claim box, 0: open-addressing hash
     int32_t lcap;      // visit-list entries per pass (capacity)
     int32_t spin_sleep;  // 1: idle waves of the pair dataflow sleep between polls (many tiles per CU)
+    int32_t threads;     // workgroup size this type's tiles want (a shared launch may bring more: the surplus waves exit)
     int32_t gens;        // hash generations kept alive (2; n_substeps when there is one collision pass per sub-step)
     int32_t pair_cache;  // 1: LDS holds lcap more 16-byte records (per-pair projection terms, see Tile::pinv)
     EggStatus *status;

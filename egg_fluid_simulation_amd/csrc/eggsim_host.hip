@@ -29,6 +29,8 @@ extern "C" __global__ void egg_step_kernel_wide(EggStepArgs A);
 extern "C" __global__ void egg_env_bounds_kernel(const double *, const double *, const double *, const double *, const double *, int,
                                                    unsigned long long *);
 extern "C" __global__ void egg_env_sums_kernel(const double *, const double *, const double *, const double *, int, double *);
+extern "C" __global__ void egg_step_kernel_pair(EggStepArgs A, EggStepArgs B);
+extern "C" __global__ void egg_step_kernel_pair_occ(EggStepArgs A, EggStepArgs B);
 extern "C" __global__ void egg_step_kernel_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gs_mg(EggStepArgs A);
@@ -145,6 +147,8 @@ struct System {  // one particle type
     // boxes, their last-sub-step travel
     DevBuf<int32_t> d_out;
     int parity = 0;  // status block of the most recent launch
+    hipStream_t wait_stream = nullptr;  // stream the most recent launch of this type went to (the white one when fused)
+    int timing_from = 0;                // type whose events time the most recent launch
     int gens = 2;    // hash generations the kernel keeps (n_substeps when n_collision_steps == 1, see PassCtx)
     std::vector<Box> aabb;  // host copy of the atoms' occupied cells
     bool aabb_valid = false;
@@ -207,6 +211,7 @@ struct egg_handle {
     egg_stats stats{};
     std::string error;
     int opt_margin = 2;
+    int opt_no_fuse = 0;      // 1: never put both types into one launch
     int opt_tile_target = 60;  // islands smaller than a wave share one (a 15-particle yolk blob uses a quarter of its lanes)
     int opt_timing = 0;
     int opt_force_single = 0;
@@ -603,8 +608,12 @@ int retile(egg_handle *h, int which) {
             np += s.atoms[(size_t)a].count;
             one.box = grow(one.box, claim[(size_t)a]);
         }
+        // independent islands share a tile only while the joint claim box stays small enough for the dense cell
+        // grid: a tile spanning the scene falls back to the hash table, which made such tiles (and with them
+        // the whole launch) 7x slower
+        auto grid_cells = [](const Box &b) { return ((int64_t)b.hi_x - b.lo_x + 4) * ((int64_t)b.hi_y - b.lo_y + 4); };
         if (target > 0 && !tiles.empty() && tiles.back().particles + np <= target &&
-            extent(grow(tiles.back().box, one.box)) <= 60000) {
+            extent(grow(tiles.back().box, one.box)) <= 60000 && grid_cells(grow(tiles.back().box, one.box)) <= 2048) {
             // independent islands may share a tile (fills the wave's lanes in the pair executor)
             TileTmp &tt = tiles.back();
             tt.atoms.insert(tt.atoms.end(), isl.begin(), isl.end());
@@ -707,7 +716,9 @@ int retile(egg_handle *h, int which) {
         if (!lc.global_lists && !lc.global_state && s.gens <= 2) {
             int spread = h->opt_spread;
             // (two such workgroups do not fit one CU's register file, so: at most one tile per CU)
-            if (spread <= 0) spread = (lc.n_tiles <= h->prop.multiProcessorCount) ? 3 : 1;
+            // -- and only while the white tiles do not fill the chip anyway (then the types share one launch)
+            const bool chip_shared = which == 1 && h->stats.n_tiles[0] > h->prop.multiProcessorCount;
+            if (spread <= 0) spread = (lc.n_tiles <= h->prop.multiProcessorCount && !chip_shared) ? 3 : 1;
             const int wide_threads = egg_step_threads(lc.nmax, spread);
             if (spread > 1 && wide_threads <= 512 && wide_threads >= 3 * lc.nmax) {
                 threads = wide_threads;
@@ -764,12 +775,13 @@ Env make_env(const egg_config &c, double sub_delta, int64_t n) {
     return e;
 }
 
-int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
+// Start of a launch of one type on `stream`: next status parity, upload of the tile / target image if it changed.
+int launch_prologue(egg_handle *h, int which, hipStream_t stream) {
     System &s = h->sys[which];
-    if (s.n == 0 || s.classes.empty()) return EGG_OK;
     s.parity ^= 1;  // this launch's status block; it re-initialises the other one for the next launch
     s.aabb_on_device = false;  // the launch overwrites the atoms' boxes
     s.out_copied = false;
+    s.wait_stream = stream;
     const size_t na = s.atoms.size();
     if (s.meta_dirty) {
         auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -781,7 +793,7 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         s.meta_off_tatoms = s.meta_off_tbegin + up16(nt * 4);
         const size_t bytes = s.meta_off_tatoms + up16(s.tile_atoms.size() * 4 + 4);
         HIP_TRY(h, s.stage_up.reserve(bytes));
-        HIP_TRY(h, s.d_meta.reserve(bytes, false, s.stream));
+        HIP_TRY(h, s.d_meta.reserve(bytes, false, stream));
         unsigned char *b = s.stage_up.p;
         memcpy(b, s.h_tx.data(), na * 8);
         memcpy(b + s.meta_off_ty, s.h_ty.data(), na * 8);
@@ -791,62 +803,96 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         memcpy(b + s.meta_off_tatoms, s.tile_atoms.data(), s.tile_atoms.size() * 4);
         // safe to reuse the staging image: every earlier copy out of it has completed (each step ends
         // with a stream synchronise)
-        HIP_TRY(h, hipMemcpyAsync(s.d_meta.p, b, bytes, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(h, hipMemcpyAsync(s.d_meta.p, b, bytes, hipMemcpyHostToDevice, stream));
         s.meta_dirty = false;
     }
+    return EGG_OK;
+}
+
+void fill_args(egg_handle *h, int which, const LaunchClass &lc, const Env &env, int S, int C, EggStepArgs &A) {
+    System &s = h->sys[which];
+    memset(&A, 0, sizeof A);
+    const int in = s.cur, out = s.cur ^ 1;
+    A.x_in = s.x[in].p;
+    A.y_in = s.y[in].p;
+    A.vx_in = s.vx[in].p;
+    A.vy_in = s.vy[in].p;
+    A.x_out = s.x[out].p;
+    A.y_out = s.y[out].p;
+    A.vx_out = s.vx[out].p;
+    A.vy_out = s.vy[out].p;
+    A.inv_mass = s.inv_mass.p;
+    A.radius = s.radius.p;
+    A.atom_offset = s.d_atom_offset.p;
+    A.atom_count = s.d_atom_count.p;
+    A.atom_batch = s.d_atom_batch.p;
+    A.atom_tx = (const double *)s.d_meta.p;
+    A.atom_ty = (const double *)(s.d_meta.p + s.meta_off_ty);
+    A.atom_fd = (const double *)(s.d_meta.p + s.meta_off_fd);
+    A.atom_claim = (const int32_t *)(s.d_meta.p + s.meta_off_claim);
+    A.atom_aabb_out = d_aabb(s);
+    A.atom_fail = s.d_atom_fail.p;
+    A.atom_disp_out = d_disp(s);
+    A.tile_atom_begin = (const int32_t *)(s.d_meta.p + s.meta_off_tbegin) + lc.first_tile;
+    A.tile_atoms = (const int32_t *)(s.d_meta.p + s.meta_off_tatoms);
+    A.n_tiles = lc.n_tiles;
+    A.sub_delta = env.sub_delta;
+    A.damping = env.damping;
+    A.follow_compliance = env.follow_c;
+    A.collision_compliance = env.collision_c;
+    A.overlap_factor = s.cfg.collision_overlap_factor;
+    A.cell_size = env.cell;
+    A.eps = s.cfg.eps;
+    A.budget = env.budget;
+    A.single_tile = (s.single_tile || h->opt_force_single) ? 1 : 0;
+    A.n_substeps = S;
+    A.n_collision_steps = C;
+    A.nmax = lc.nmax;
+    A.amax = lc.amax;
+    A.ccap = lc.ccap;
+    A.use_grid = lc.use_grid;
+    A.lcap = lc.lcap;
+    // more tiles than the chip can hold at one per CU: idle waves yield their issue slots
+    A.spin_sleep = (h->opt_spin_sleep < 0) ? ((lc.n_tiles > 2 * h->prop.multiProcessorCount || lc.global_state) ? 1 : 0)
+                                           : h->opt_spin_sleep;
+    A.pair_cache = lc.pair_cache;
+    A.threads = lc.threads;
+    A.gens = s.gens;
+    A.status = d_stat(s, s.parity);
+    A.status_next = d_stat(s, s.parity ^ 1);
+    A.scratch = s.d_scratch.p + lc.scratch_offset;
+    A.scratch_stride = lc.scratch_stride;
+}
+
+// End of a launch: one copy brings back the status blocks and, behind them, the atoms' end-of-step cell boxes
+// and last-sub-step travel: the next tiling (every step while targets move) then needs no further round trip.
+int launch_epilogue(egg_handle *h, int which, hipStream_t stream) {
+    System &s = h->sys[which];
+    const size_t na = s.atoms.size();
+    const bool with_boxes = na && na <= (size_t)4 << 20;  // 32 B per atom; beyond that the boxes are fetched when a tiling needs them
+    const size_t bytes = (2 * kStatInts + (with_boxes ? 8 * na : 0)) * sizeof(int32_t);
+    HIP_TRY(h, s.stage_down.reserve(bytes));
+    HIP_TRY(h, hipMemcpyAsync(s.stage_down.p, s.d_out.p, bytes, hipMemcpyDeviceToHost, stream));
+    s.h_status = (EggStatus *)(s.stage_down.p + (size_t)s.parity * kStatInts * sizeof(int32_t));
+    s.out_copied = with_boxes;
+    return EGG_OK;
+}
+
+// the throughput-tuned variant: judged by the white tiles (a yolk wave should not hold 167 registers on a full chip)
+bool use_occ_variant(const egg_handle *h, const LaunchClass &lc) {
+    return std::max<int64_t>(lc.n_tiles, h->stats.n_tiles[0]) >= 4 * (int64_t)h->prop.multiProcessorCount;
+}
+
+int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
+    System &s = h->sys[which];
+    if (s.n == 0 || s.classes.empty()) return EGG_OK;
+    int rc = launch_prologue(h, which, s.stream);
+    if (rc != EGG_OK) return rc;
+    s.timing_from = which;
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev0, s.stream));
     for (const LaunchClass &lc : s.classes) {
         EggStepArgs A;
-        memset(&A, 0, sizeof A);
-        const int in = s.cur, out = s.cur ^ 1;
-        A.x_in = s.x[in].p;
-        A.y_in = s.y[in].p;
-        A.vx_in = s.vx[in].p;
-        A.vy_in = s.vy[in].p;
-        A.x_out = s.x[out].p;
-        A.y_out = s.y[out].p;
-        A.vx_out = s.vx[out].p;
-        A.vy_out = s.vy[out].p;
-        A.inv_mass = s.inv_mass.p;
-        A.radius = s.radius.p;
-        A.atom_offset = s.d_atom_offset.p;
-        A.atom_count = s.d_atom_count.p;
-        A.atom_batch = s.d_atom_batch.p;
-        A.atom_tx = (const double *)s.d_meta.p;
-        A.atom_ty = (const double *)(s.d_meta.p + s.meta_off_ty);
-        A.atom_fd = (const double *)(s.d_meta.p + s.meta_off_fd);
-        A.atom_claim = (const int32_t *)(s.d_meta.p + s.meta_off_claim);
-        A.atom_aabb_out = d_aabb(s);
-        A.atom_fail = s.d_atom_fail.p;
-        A.atom_disp_out = d_disp(s);
-        A.tile_atom_begin = (const int32_t *)(s.d_meta.p + s.meta_off_tbegin) + lc.first_tile;
-        A.tile_atoms = (const int32_t *)(s.d_meta.p + s.meta_off_tatoms);
-        A.n_tiles = lc.n_tiles;
-        A.sub_delta = env.sub_delta;
-        A.damping = env.damping;
-        A.follow_compliance = env.follow_c;
-        A.collision_compliance = env.collision_c;
-        A.overlap_factor = s.cfg.collision_overlap_factor;
-        A.cell_size = env.cell;
-        A.eps = s.cfg.eps;
-        A.budget = env.budget;
-        A.single_tile = (s.single_tile || h->opt_force_single) ? 1 : 0;
-        A.n_substeps = S;
-        A.n_collision_steps = C;
-        A.nmax = lc.nmax;
-        A.amax = lc.amax;
-        A.ccap = lc.ccap;
-        A.use_grid = lc.use_grid;
-        A.lcap = lc.lcap;
-        // more tiles than the chip can hold at one per CU: idle waves yield their issue slots
-        A.spin_sleep = (h->opt_spin_sleep < 0) ? ((lc.n_tiles > 2 * h->prop.multiProcessorCount || lc.global_state) ? 1 : 0)
-                                               : h->opt_spin_sleep;
-        A.pair_cache = lc.pair_cache;
-        A.gens = s.gens;
-        A.status = d_stat(s, s.parity);
-        A.status_next = d_stat(s, s.parity ^ 1);
-        A.scratch = s.d_scratch.p + lc.scratch_offset;
-        A.scratch_stride = lc.scratch_stride;
+        fill_args(h, which, lc, env, S, C, A);
         const dim3 grid((unsigned)lc.n_tiles), block((unsigned)lc.threads);
         if (s.gens > 2) {  // more than two hash generations: the variants with the general list builder
             if (lc.global_state)
@@ -861,7 +907,7 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
             hipLaunchKernelGGL(egg_step_kernel_gl, grid, block, lc.lds, s.stream, A);
         else if (lc.wide)
             hipLaunchKernelGGL(egg_step_kernel_wide, grid, block, lc.lds, s.stream, A);
-        else if (std::max<int64_t>(lc.n_tiles, h->stats.n_tiles[0]) >= 4 * h->prop.multiProcessorCount)  // throughput regime (judged by the white tiles: a yolk wave should not hold 167 registers on a full chip): residency over spill-freedom
+        else if (use_occ_variant(h, lc))  // throughput regime: residency over spill-freedom
             hipLaunchKernelGGL(egg_step_kernel_occ, grid, block, lc.lds, s.stream, A);
         else
             hipLaunchKernelGGL(egg_step_kernel, grid, block, lc.lds, s.stream, A);
@@ -869,14 +915,51 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         h->stats.kernel_launches++;
     }
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev1, s.stream));
-    // one copy brings back the status blocks and, behind them, the atoms' end-of-step cell boxes and
-    // last-sub-step travel: the next tiling (every step while targets move) then needs no further round trip
-    const bool with_boxes = na && na <= (size_t)4 << 20;  // 32 B per atom; beyond that the boxes are fetched when a tiling needs them
-    const size_t bytes = (2 * kStatInts + (with_boxes ? 8 * na : 0)) * sizeof(int32_t);
-    HIP_TRY(h, s.stage_down.reserve(bytes));
-    HIP_TRY(h, hipMemcpyAsync(s.stage_down.p, s.d_out.p, bytes, hipMemcpyDeviceToHost, s.stream));
-    s.h_status = (EggStatus *)(s.stage_down.p + (size_t)s.parity * kStatInts * sizeof(int32_t));
-    s.out_copied = with_boxes;
+    return launch_epilogue(h, which, s.stream);
+}
+
+// Both types as one grid (egg_step_kernel_pair) when each is a single class of LDS tiles and the chip is
+// shared by several tiles per CU; otherwise one launch per type and class on the type's own stream.
+bool can_fuse(const egg_handle *h) {
+    if (h->opt_no_fuse) return false;
+    // measured: 1024 batches 0.72 -> 0.57 ms per step, 4096: 1.87 -> 1.77; from ~16384 the yolk tiles' share of
+    // the larger LDS allocation costs more than their late finish (6.13 -> 6.24), hence the upper bound
+    if (h->stats.n_tiles[0] > 32 * (int64_t)h->prop.multiProcessorCount) return false;
+    for (int w = 0; w < 2; ++w) {
+        const System &s = h->sys[w];
+        if (s.n == 0 || s.classes.size() != 1 || s.gens > 2) return false;
+        const LaunchClass &lc = s.classes[0];
+        if (lc.wide || lc.global_lists || lc.global_state) return false;
+    }
+    return true;
+}
+
+int launch_fused(egg_handle *h, const Env *env, int S, int C) {
+    System &W = h->sys[0], &Y = h->sys[1];
+    const hipStream_t stream = W.stream;
+    for (int w = 0; w < 2; ++w) {
+        int rc = launch_prologue(h, w, stream);
+        if (rc != EGG_OK) return rc;
+        h->sys[w].timing_from = 0;
+    }
+    EggStepArgs A, B;
+    const LaunchClass &lw = W.classes[0], &ly = Y.classes[0];
+    fill_args(h, 0, lw, env[0], S, C, A);
+    fill_args(h, 1, ly, env[1], S, C, B);
+    const dim3 grid((unsigned)(lw.n_tiles + ly.n_tiles)), block((unsigned)std::max(lw.threads, ly.threads));
+    const size_t lds = std::max(lw.lds, ly.lds);
+    if (h->opt_timing) HIP_TRY(h, hipEventRecord(W.ev0, stream));
+    if (use_occ_variant(h, lw))
+        hipLaunchKernelGGL(egg_step_kernel_pair_occ, grid, block, lds, stream, A, B);
+    else
+        hipLaunchKernelGGL(egg_step_kernel_pair, grid, block, lds, stream, A, B);
+    HIP_TRY(h, hipGetLastError());
+    h->stats.kernel_launches++;
+    if (h->opt_timing) HIP_TRY(h, hipEventRecord(W.ev1, stream));
+    for (int w = 0; w < 2; ++w) {
+        int rc = launch_epilogue(h, w, stream);
+        if (rc != EGG_OK) return rc;
+    }
     return EGG_OK;
 }
 
@@ -965,15 +1048,15 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
         if (!(phase == kEnd && attempt == 0)) {  // kEnd: the first attempt is already in flight
             int rc = prepare_tiles(h);
             if (rc != EGG_OK) return rc;
-            // Launch order: white first (with at most a few tiles per CU it is the critical path).  On a chip
-            // saturated many times over, yolk tiles queued behind the white ones trickled in late (2048
-            // batches: step 1.70 ms white first, 1.22 ms yolk first; no difference from 4096 up, white first
-            // better up to 1536), so from 8 white tiles per CU the yolk launch goes first.
-            const bool yolk_first = h->stats.n_tiles[0] >= 8 * (int64_t)h->prop.multiProcessorCount;
-            for (int k = 0; k < 2; ++k) {
-                const int w = yolk_first ? 1 - k : k;
-                rc = launch_type(h, w, env[w], S, C);
+            if (can_fuse(h)) {
+                rc = launch_fused(h, env, S, C);
                 if (rc != EGG_OK) return rc;
+            } else {
+                // white first: with at most a few tiles per CU it is the critical path
+                for (int w = 0; w < 2; ++w) {
+                    rc = launch_type(h, w, env[w], S, C);
+                    if (rc != EGG_OK) return rc;
+                }
             }
             if (phase == kBegin) return EGG_OK;
         }
@@ -982,10 +1065,11 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
         for (int w = 0; w < 2; ++w) {
             System &s = h->sys[w];
             if (s.n == 0 || s.classes.empty()) continue;
-            HIP_TRY(h, wait_step(s.stream));
+            HIP_TRY(h, wait_step(s.wait_stream ? s.wait_stream : s.stream));
             if (h->opt_timing) {
                 float t = 0;
-                HIP_TRY(h, hipEventElapsedTime(&t, s.ev0, s.ev1));
+                const System &ts = h->sys[s.timing_from];
+                HIP_TRY(h, hipEventElapsedTime(&t, ts.ev0, ts.ev1));
                 ms = std::max(ms, (double)t);
                 h->stats.kernel_ms[w] = (double)t;
             }
@@ -1207,6 +1291,10 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
             e = hipFuncSetAttribute((const void *)egg_step_kernel_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)egg_step_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_pair_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)egg_step_kernel_mg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
@@ -1902,6 +1990,9 @@ int egg_set_option(egg_handle *h, int option, double value) {
             if (!(value >= 0 && value <= 4) || value != (int)value)
                 return fail(h, EGG_ERR_INVALID_ARGUMENT, "threads per particle must be 0 (automatic), 1, 2, 3 or 4");
             h->opt_spread = (int)value;
+            return EGG_OK;
+        case EGG_OPT_FUSE_TYPES:
+            h->opt_no_fuse = value == 0;
             return EGG_OK;
         case EGG_OPT_FORCE_GLOBAL_STATE:
             h->opt_force_global_state = value != 0;

@@ -708,13 +708,14 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
 // counters (global memory gives no issue-order guarantee).  Slow, but any island up to the index
 // limit (32766 particles) is stepped exactly.
 template <bool GLOBAL_LISTS, bool GLOBAL_STATE, bool WIDE = false, bool MULTIGEN = false>
-__device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
+__device__ __forceinline__ void egg_step_body(const EggStepArgs &A, const int tile = (int)blockIdx.x) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int nthreads = blockDim.x;
+    // In a launch shared with the other particle type the workgroup is sized for the larger tiles: the waves
+    // this type's tiles do not need leave at once (a finished wave no longer takes part in s_barrier).
+    const int nthreads = (A.threads > 0 && A.threads < (int)blockDim.x) ? A.threads : (int)blockDim.x;
     const int lane = tid & 63;
-    const int tile = blockIdx.x;
-    if (tile >= A.n_tiles) return;
+    if (tile >= A.n_tiles || tid >= nthreads) return;
     PROF_DECL
 
     // ---------------------------------------------------------------- LDS carve
@@ -724,7 +725,7 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A) {
         unsigned char *p = GLOBAL_STATE ? A.scratch + (size_t)tile * A.scratch_stride : smem;
         t.pos = (double2 *)carve(p, n * 16);
         t.wr = (double2 *)carve(p, n * 16);
-        const bool state_in_lds = A.nmax > (int)blockDim.x;
+        const bool state_in_lds = A.nmax > nthreads;
         t.prev = (double2 *)carve(p, state_in_lds ? n * 16 : 0);
         t.vel = (double2 *)carve(p, state_in_lds ? n * 16 : 0);
         t.atx = (double *)carve(p, a * 8);
@@ -1343,6 +1344,23 @@ egg_step_kernel_wide(EggStepArgs A) {
 }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true, false>(A); }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs(EggStepArgs A) { egg_step_body<true, true>(A); }
+// Both particle types in ONE launch (tiles of B first, then tiles of A).  Two launches on two streams share a
+// saturated chip badly: the second one's tiles queue behind the first one's and finish ~0.12 ms after them
+// whatever the order or the stream priorities; as the first blocks of the same grid they start at once.
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+egg_step_kernel_pair(EggStepArgs A, EggStepArgs B) {
+    if ((int)blockIdx.x < B.n_tiles)
+        egg_step_body<false, false>(B, (int)blockIdx.x);
+    else
+        egg_step_body<false, false>(A, (int)blockIdx.x - B.n_tiles);
+}
+extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_pair_occ(EggStepArgs A, EggStepArgs B) {
+    if ((int)blockIdx.x < B.n_tiles)
+        egg_step_body<false, false>(B, (int)blockIdx.x);
+    else
+        egg_step_body<false, false>(A, (int)blockIdx.x - B.n_tiles);
+}
+
 // More than two hash generations alive (one collision pass per sub-step, three or more sub-steps): the same
 // three storage variants with the general list builder compiled in.  A rare configuration; no wide / occupancy
 // tuned instances.

@@ -217,7 +217,8 @@ enum {
     EGG_OPT_SPIN_SLEEP,             /* -1 auto, 0 never, 1 always: idle dataflow waves sleep between polls */
     EGG_OPT_BUDGET_PARTICLES_WHITE, /* multi-GPU: N of the collision budget 0.05 N^2 (L:1752-1753) = particles of ALL ranks; -1 = local */
     EGG_OPT_BUDGET_PARTICLES_YOLK,
-    EGG_OPT_FORCE_GLOBAL_STATE      /* test hook: 1 = every tile keeps its state in global memory (the large-island fallback) */
+    EGG_OPT_FORCE_GLOBAL_STATE,     /* test hook: 1 = every tile keeps its state in global memory (the large-island fallback) */
+    EGG_OPT_FUSE_TYPES              /* 1 (default): white and yolk tiles share one launch when the chip holds several tiles per CU; 0: one launch per type */
 };
 int egg_set_option(egg_handle *h, int option, double value);
 

@@ -108,3 +108,8 @@ static inline int egg_step_threads(int nmax, int spread) {
     int t = (nmax * spread + EGG_WAVE - 1) / EGG_WAVE * EGG_WAVE;
     return t < EGG_WAVE ? EGG_WAVE : (t > 1024 ? 1024 : t);
 }
+
+// the arguments of up to four launch classes sharing one launch (egg_step_kernel_multi*); unused slots have n_tiles = 0
+struct EggStepArgs4 {
+    EggStepArgs a[4];
+};

@@ -29,8 +29,9 @@ extern "C" __global__ void egg_step_kernel_wide(EggStepArgs A);
 extern "C" __global__ void egg_env_bounds_kernel(const double *, const double *, const double *, const double *, const double *, int,
                                                    unsigned long long *);
 extern "C" __global__ void egg_env_sums_kernel(const double *, const double *, const double *, const double *, int, double *);
-extern "C" __global__ void egg_step_kernel_pair(EggStepArgs A, EggStepArgs B);
-extern "C" __global__ void egg_step_kernel_pair_occ(EggStepArgs A, EggStepArgs B);
+extern "C" __global__ void egg_step_kernel_multi(EggStepArgs4 P);
+extern "C" __global__ void egg_step_kernel_multi_occ(EggStepArgs4 P);
+extern "C" __global__ void egg_step_kernel_multi_wide(EggStepArgs4 P);
 extern "C" __global__ void egg_step_kernel_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gl_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gs_mg(EggStepArgs A);
@@ -918,41 +919,57 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     return launch_epilogue(h, which, s.stream);
 }
 
-// Both types as one grid (egg_step_kernel_pair) when each is a single class of LDS tiles and the chip is
-// shared by several tiles per CU; otherwise one launch per type and class on the type's own stream.
+// All launch classes of both types as one grid (egg_step_kernel_multi*) when there are at most four, all of
+// LDS tiles, all wide or all narrow; otherwise one launch per class on the type's own stream.
 bool can_fuse(const egg_handle *h) {
     if (h->opt_no_fuse) return false;
-    // measured: 1024 batches 0.72 -> 0.57 ms per step, 4096: 1.87 -> 1.77; from ~16384 the yolk tiles' share of
-    // the larger LDS allocation costs more than their late finish (6.13 -> 6.24), hence the upper bound
-    if (h->stats.n_tiles[0] > 32 * (int64_t)h->prop.multiProcessorCount) return false;
+    // measured (ms per step, one launch vs one per type): 10 batches 0.34 vs 0.51, 512: 0.47 vs 0.66, 1024: 0.59 vs
+    // 0.75, 4096: 1.82 vs 1.92; from 8192 on the small tiles' share of the larger LDS allocation costs more than
+    // their late finish (3.37 vs 3.33, 16384: 6.24 vs 6.13), hence the upper bound
+    if (h->stats.n_tiles[0] > 16 * (int64_t)h->prop.multiProcessorCount) return false;
+    size_t n_classes = 0;
+    int wide = -1;
     for (int w = 0; w < 2; ++w) {
         const System &s = h->sys[w];
-        if (s.n == 0 || s.classes.size() != 1 || s.gens > 2) return false;
-        const LaunchClass &lc = s.classes[0];
-        if (lc.wide || lc.global_lists || lc.global_state) return false;
+        if (s.n == 0 || s.classes.empty() || s.gens > 2) return false;
+        for (const LaunchClass &lc : s.classes) {
+            if (lc.global_lists || lc.global_state) return false;
+            if (wide >= 0 && wide != lc.wide) return false;
+            wide = lc.wide;
+            ++n_classes;
+        }
     }
-    return true;
+    return n_classes <= 4;
 }
 
 int launch_fused(egg_handle *h, const Env *env, int S, int C) {
-    System &W = h->sys[0], &Y = h->sys[1];
+    System &W = h->sys[0];
     const hipStream_t stream = W.stream;
-    for (int w = 0; w < 2; ++w) {
+    EggStepArgs4 P;
+    memset(&P, 0, sizeof P);
+    int k = 0, threads = 0;
+    int64_t tiles = 0;
+    size_t lds = 0;
+    for (int w = 1; w >= 0; --w) {  // yolk classes first: the small tiles start first
         int rc = launch_prologue(h, w, stream);
         if (rc != EGG_OK) return rc;
         h->sys[w].timing_from = 0;
+        for (const LaunchClass &lc : h->sys[w].classes) {
+            fill_args(h, w, lc, env[w], S, C, P.a[k++]);
+            threads = std::max(threads, lc.threads);
+            lds = std::max(lds, lc.lds);
+            tiles += lc.n_tiles;
+        }
     }
-    EggStepArgs A, B;
-    const LaunchClass &lw = W.classes[0], &ly = Y.classes[0];
-    fill_args(h, 0, lw, env[0], S, C, A);
-    fill_args(h, 1, ly, env[1], S, C, B);
-    const dim3 grid((unsigned)(lw.n_tiles + ly.n_tiles)), block((unsigned)std::max(lw.threads, ly.threads));
-    const size_t lds = std::max(lw.lds, ly.lds);
+    const LaunchClass &lw = W.classes[0];
+    const dim3 grid((unsigned)tiles), block((unsigned)threads);
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(W.ev0, stream));
-    if (use_occ_variant(h, lw))
-        hipLaunchKernelGGL(egg_step_kernel_pair_occ, grid, block, lds, stream, A, B);
+    if (lw.wide)
+        hipLaunchKernelGGL(egg_step_kernel_multi_wide, grid, block, lds, stream, P);
+    else if (use_occ_variant(h, lw))
+        hipLaunchKernelGGL(egg_step_kernel_multi_occ, grid, block, lds, stream, P);
     else
-        hipLaunchKernelGGL(egg_step_kernel_pair, grid, block, lds, stream, A, B);
+        hipLaunchKernelGGL(egg_step_kernel_multi, grid, block, lds, stream, P);
     HIP_TRY(h, hipGetLastError());
     h->stats.kernel_launches++;
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(W.ev1, stream));
@@ -1292,9 +1309,11 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)egg_step_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)egg_step_kernel_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)egg_step_kernel_pair_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_multi_occ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)egg_step_kernel_multi_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)egg_step_kernel_mg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)

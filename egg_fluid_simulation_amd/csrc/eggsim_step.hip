@@ -1344,22 +1344,28 @@ egg_step_kernel_wide(EggStepArgs A) {
 }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gl(EggStepArgs A) { egg_step_body<true, false>(A); }
 extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs(EggStepArgs A) { egg_step_body<true, true>(A); }
-// Both particle types in ONE launch (tiles of B first, then tiles of A).  Two launches on two streams share a
-// saturated chip badly: the second one's tiles queue behind the first one's and finish ~0.12 ms after them
-// whatever the order or the stream priorities; as the first blocks of the same grid they start at once.
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-egg_step_kernel_pair(EggStepArgs A, EggStepArgs B) {
-    if ((int)blockIdx.x < B.n_tiles)
-        egg_step_body<false, false>(B, (int)blockIdx.x);
-    else
-        egg_step_body<false, false>(A, (int)blockIdx.x - B.n_tiles);
+// Several launch classes -- of both particle types -- in ONE launch: the grid is the concatenation of the
+// classes' tiles, every class brings its own arguments (EggStepArgs::threads tells its tiles how many of
+// the workgroup's waves to keep).  Two launches on two streams overlap only if they land in different
+// hardware queues, and on a full chip the second one's tiles finish ~0.12 ms after the first's whatever the
+// order or the stream priorities; as blocks of one grid they are dispatched in order, small tiles first.
+template <bool WIDE>
+__device__ __forceinline__ void egg_step_multi(const EggStepArgs4 &P) {
+    int tile = (int)blockIdx.x, k = 0;
+    while (k < 3 && tile >= P.a[k].n_tiles) {
+        tile -= P.a[k].n_tiles;
+        ++k;
+    }
+    egg_step_body<false, false, WIDE>(P.a[k], tile);
 }
-extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_pair_occ(EggStepArgs A, EggStepArgs B) {
-    if ((int)blockIdx.x < B.n_tiles)
-        egg_step_body<false, false>(B, (int)blockIdx.x);
-    else
-        egg_step_body<false, false>(A, (int)blockIdx.x - B.n_tiles);
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) egg_step_kernel_multi(EggStepArgs4 P) {
+    egg_step_multi<false>(P);
 }
+extern "C" __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3)))
+egg_step_kernel_multi_wide(EggStepArgs4 P) {
+    egg_step_multi<true>(P);
+}
+extern "C" __global__ void __launch_bounds__(256, 5) egg_step_kernel_multi_occ(EggStepArgs4 P) { egg_step_multi<false>(P); }
 
 // More than two hash generations alive (one collision pass per sub-step, three or more sub-steps): the same
 // three storage variants with the general list builder compiled in.  A rare configuration; no wide / occupancy

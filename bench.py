@@ -176,9 +176,11 @@ def main():
 
     if rank == 0:
         steps_per_sec = args.steps / elapsed
-        # roofline of the dominant kernel (the white-particle launch of egg_step_kernel on this rank):
-        # algorithmic bytes of one launch / its average HIP-event duration
-        algo_bytes = ALGO_BYTES_PER_PARTICLE_STEP * n_white
+        # roofline of the dominant kernel: algorithmic bytes of one launch / its average HIP-event duration.
+        # Normally ONE launch steps the tiles of both particle types (stats fused_launch); otherwise the
+        # white-particle launch is the dominant one and the yolk launch runs beside it.
+        fused = bool(s1.get("fused_launch"))
+        algo_bytes = ALGO_BYTES_PER_PARTICLE_STEP * ((n_white + n_yolk) if fused else n_white)
         achieved = algo_bytes / (kernel_ms_white * 1e-3) / 1e9 if kernel_ms_white > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -204,8 +206,9 @@ def main():
                        "redo_steps": s1["redo_steps"] - s0["redo_steps"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "egg_step_kernel (white launch)", "kernel_ms": kernel_ms_white,
-                         "kernel_ms_yolk_launch": kernel_ms_yolk, "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": "egg_step_kernel_multi* (one launch, white + yolk tiles)" if fused else "egg_step_kernel* (white launch)",
+                         "kernel_ms": kernel_ms_white,
+                         "kernel_ms_yolk_launch": None if fused else kernel_ms_yolk, "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "592 B/particle/step byte model of SURVEY.md 8d; the fused kernel moves far fewer "
                                  "HBM bytes and is bound by the serial pair-dependency chain in FP64, see DESIGN.md"},
         }

@@ -67,7 +67,7 @@ class EggStats(C.Structure):
                 ("n_tiles", C.c_int64 * 2), ("max_tile_particles", C.c_int64 * 2),
                 ("last_step_kernel_ms", C.c_double), ("single_tile", C.c_int64 * 2),
                 ("kernel_ms", C.c_double * 2), ("kernel_ms_sum", C.c_double * 2), ("timed_steps", C.c_int64),
-                ("max_pass_visits", C.c_int64 * 2), ("budget", C.c_double * 2)]
+                ("max_pass_visits", C.c_int64 * 2), ("budget", C.c_double * 2), ("fused_launch", C.c_int64)]
 
 
 # every symbol include/eggsim.h declares, with its signature

@@ -947,15 +947,18 @@ int launch_fused(egg_handle *h, const Env *env, int S, int C) {
     const hipStream_t stream = W.stream;
     EggStepArgs4 P;
     memset(&P, 0, sizeof P);
-    int k = 0, threads = 0;
+    // slot 0: the first white class (the bulk of the work); slots 1..3: every other class, yolk first -- the
+    // kernel puts their tiles at the front of the grid, so the small tiles start first
+    int k = 1, threads = 0;
     int64_t tiles = 0;
     size_t lds = 0;
-    for (int w = 1; w >= 0; --w) {  // yolk classes first: the small tiles start first
+    for (int w = 1; w >= 0; --w) {
         int rc = launch_prologue(h, w, stream);
         if (rc != EGG_OK) return rc;
         h->sys[w].timing_from = 0;
-        for (const LaunchClass &lc : h->sys[w].classes) {
-            fill_args(h, w, lc, env[w], S, C, P.a[k++]);
+        for (size_t c = 0; c < h->sys[w].classes.size(); ++c) {
+            const LaunchClass &lc = h->sys[w].classes[c];
+            fill_args(h, w, lc, env[w], S, C, (w == 0 && c == 0) ? P.a[0] : P.a[k++]);
             threads = std::max(threads, lc.threads);
             lds = std::max(lds, lc.lds);
             tiles += lc.n_tiles;
@@ -1065,7 +1068,8 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
         if (!(phase == kEnd && attempt == 0)) {  // kEnd: the first attempt is already in flight
             int rc = prepare_tiles(h);
             if (rc != EGG_OK) return rc;
-            if (can_fuse(h)) {
+            h->stats.fused_launch = can_fuse(h) ? 1 : 0;
+            if (h->stats.fused_launch) {
                 rc = launch_fused(h, env, S, C);
                 if (rc != EGG_OK) return rc;
             } else {

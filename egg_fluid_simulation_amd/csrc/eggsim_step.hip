@@ -707,8 +707,9 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
 // algorithm, HBM/L2 latency on every access, workgroup-scope release/acquire around the dataflow
 // counters (global memory gives no issue-order guarantee).  Slow, but any island up to the index
 // limit (32766 particles) is stepped exactly.
-template <bool GLOBAL_LISTS, bool GLOBAL_STATE, bool WIDE = false, bool MULTIGEN = false>
-__device__ __forceinline__ void egg_step_body(const EggStepArgs &A, const int tile = (int)blockIdx.x) {
+// (Args: EggStepArgs, or the same struct in the constant address space when the launch carries several)
+template <bool GLOBAL_LISTS, bool GLOBAL_STATE, bool WIDE = false, bool MULTIGEN = false, class Args = EggStepArgs>
+__device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (int)blockIdx.x) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
     // In a launch shared with the other particle type the workgroup is sized for the larger tiles: the waves
@@ -829,11 +830,12 @@ __device__ __forceinline__ void egg_step_body(const EggStepArgs &A, const int ti
         if (off > A.nmax || na > A.amax) atomicExch(&A.status->fail_overflow, 1);
     }
     __syncthreads();
-    const int n = min(t.sc[2], A.nmax);
+    // (workgroup-uniform values read back from LDS: tell the compiler, so that they live in scalar registers)
+    const int n = __builtin_amdgcn_readfirstlane(min(t.sc[2], A.nmax));
     t.n = n;
-    const int org_x = t.sc[3], org_y = t.sc[4];
-    t.gw = t.sc[6];
-    t.ncell = A.use_grid ? (int)min((long long)t.sc[6] * t.sc[7], (long long)A.ccap) : A.ccap;
+    const int org_x = __builtin_amdgcn_readfirstlane(t.sc[3]), org_y = __builtin_amdgcn_readfirstlane(t.sc[4]);
+    t.gw = __builtin_amdgcn_readfirstlane(t.sc[6]);
+    t.ncell = A.use_grid ? __builtin_amdgcn_readfirstlane((int)min((long long)t.sc[6] * t.sc[7], (long long)A.ccap)) : A.ccap;
 
     for (int k = 0; k < na; ++k) {
         int atom = A.tile_atoms[a_begin + k];
@@ -1349,14 +1351,27 @@ extern "C" __global__ void __launch_bounds__(1024) egg_step_kernel_gs(EggStepArg
 // the workgroup's waves to keep).  Two launches on two streams overlap only if they land in different
 // hardware queues, and on a full chip the second one's tiles finish ~0.12 ms after the first's whatever the
 // order or the stream priorities; as blocks of one grid they are dispatched in order, small tiles first.
+// The grid is: tiles of the secondary classes (slots 1..3 of the parameter, small tiles), then the tiles of
+// the primary class (slot 0: the white tiles, nearly all of the work).  The primary class reads its arguments
+// like the single-class kernels do; the secondary ones read theirs where they lie in the kernel-argument
+// segment (scalar loads at a uniform offset) -- indexing the by-value parameter made the compiler stage all
+// four structs through scratch for every lane.
+typedef const __attribute__((address_space(4))) EggStepArgs EggStepArgsK;
 template <bool WIDE>
 __device__ __forceinline__ void egg_step_multi(const EggStepArgs4 &P) {
-    int tile = (int)blockIdx.x, k = 0;
-    while (k < 3 && tile >= P.a[k].n_tiles) {
-        tile -= P.a[k].n_tiles;
+    const int n_secondary = P.a[1].n_tiles + P.a[2].n_tiles + P.a[3].n_tiles;
+    int tile = (int)blockIdx.x;
+    if (tile >= n_secondary) {
+        egg_step_body<false, false, WIDE>(P.a[0], tile - n_secondary);
+        return;
+    }
+    EggStepArgsK *K = (EggStepArgsK *)__builtin_amdgcn_kernarg_segment_ptr();  // EggStepArgs4 is the only parameter
+    int k = 1;
+    while (k < 3 && tile >= K[k].n_tiles) {
+        tile -= K[k].n_tiles;
         ++k;
     }
-    egg_step_body<false, false, WIDE>(P.a[k], tile);
+    egg_step_body<false, false, WIDE, false, EggStepArgsK>(K[k], tile);
 }
 extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) egg_step_kernel_multi(EggStepArgs4 P) {
     egg_step_multi<false>(P);

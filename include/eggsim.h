@@ -199,6 +199,7 @@ typedef struct {
     int64_t timed_steps;
     int64_t max_pass_visits[2]; /* most pairs visited in one collision pass of the most recent _step, per type */
     double budget[2];           /* max_collision_fraction * N^2 of the most recent _step (L:1752-1753), per type */
+    int64_t fused_launch;       /* 1 if the most recent _step ran both types' tiles in one launch (kernel_ms[0] == kernel_ms[1] is then that launch) */
 } egg_stats;
 int egg_get_stats(egg_handle *h, egg_stats *out);
 

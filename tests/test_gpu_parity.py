@@ -157,7 +157,7 @@ def test_result_is_independent_of_tiling(egg):
     from egg_fluid_simulation_amd import _ffi
     xs, ys = _grid(36)  # the forced single tile (5652 white particles) runs in the global-memory-state kernel
     ref = None
-    for opts in ({}, {_ffi.OPT_TILE_TARGET_PARTICLES: 0}, {_ffi.OPT_TILE_TARGET_PARTICLES: 700}, {_ffi.OPT_CLAIM_MARGIN_CELLS: 6},
+    for opts in ({}, {_ffi.OPT_TILE_TARGET_PARTICLES: 0}, {_ffi.OPT_FUSE_TYPES: 0}, {_ffi.OPT_TILE_TARGET_PARTICLES: 700}, {_ffi.OPT_CLAIM_MARGIN_CELLS: 6},
                  {_ffi.OPT_FORCE_SINGLE_TILE: 1}):
         h = egg.SimulationHandler()
         for k, v in opts.items():
@@ -173,6 +173,28 @@ def test_result_is_independent_of_tiling(egg):
             assert h.stats()["n_tiles"][0] == 36
         else:
             assert all(np.array_equal(a, b) for a, b in zip(ref, state)), opts
+
+
+def test_one_launch_for_both_types_on_a_shared_chip(egg, oracle_mod):
+    """300 batches: more white tiles than CUs, so the narrow kernel variants run and -- by default -- the tiles
+    of both types (three launch classes here) go into ONE grid; with one launch per class on two streams the
+    bits must be the same, and both must be the oracle's"""
+    from egg_fluid_simulation_amd import _ffi
+    xs, ys = _grid(300)
+    h, o, _ = _run_both(egg, oracle_mod, xs, ys, 3, True)
+    assert h.stats()["fused_launch"] == 1
+    _assert_same_state(h, o)
+    h2 = egg.SimulationHandler()
+    h2.set_option(_ffi.OPT_FUSE_TYPES, 0)
+    ids = h2.add_many(xs, ys, 50, 15)
+    for k in range(3):
+        dx, dy = circle_target((0.0, 0.0), k)
+        h2.set_target_positions(ids, xs + dx, ys + dy)
+        assert h2.update(1 / 60) == 1
+    assert h2.stats()["fused_launch"] == 0
+    for w in (WHITE, YOLK):
+        for f in ("x", "y", "vx", "vy"):
+            assert np.array_equal(h.download(w, f), h2.download(w, f)), (w, f)
 
 
 def test_large_island_falls_back_to_global_memory_state(egg, oracle_mod):

@@ -77,3 +77,35 @@ def test_random_session_matches_oracle(egg, oracle_mod, seed):
     _same(h, o, (seed, "end"))
     for i in live:
         assert h.get_position(i) == o.get_position(i)
+
+
+def test_crowded_scene_on_a_shared_chip(egg, oracle_mod):
+    """320 batches (more white tiles than CUs: the narrow kernel variants, several launch classes in one grid)
+    wandering into each other for 30 steps: islands merge and split, claims get widened, steps get re-run"""
+    rng = np.random.default_rng(5)
+    n = 320
+    side = 18
+    xs = 100.0 + 170.0 * (np.arange(n) % side)
+    ys = 100.0 + 170.0 * (np.arange(n) // side)
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    ids = h.add_many(xs, ys, 50, 15)
+    for x, y in zip(xs, ys):
+        o.add(float(x), float(y), 50, 15)
+    vel = rng.uniform(-2.5, 2.5, (n, 2))  # neighbours meet here and there; faster and the whole scene chains into
+    # one island beyond the 32,766-particle limit of a tile
+    tx, ty = xs.copy(), ys.copy()
+    tiles_seen = []
+    for step in range(30):
+        tx += vel[:, 0]
+        ty += vel[:, 1]
+        h.set_target_positions(ids, tx, ty)
+        for i, a, b in zip(ids, tx, ty):
+            o.set_target_position(int(i), float(a), float(b))
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+        tiles_seen.append(h.stats()["n_tiles"][0])
+        if step % 10 == 9:
+            _same(h, o, step)
+    # the run starts with more white tiles than CUs (narrow variants, one grid for all classes) and ends with
+    # many islands merged
+    assert max(tiles_seen) > 256 and min(tiles_seen) < n, (tiles_seen[0], tiles_seen[-1])

@@ -144,6 +144,26 @@ def test_environment_reductions_match_the_reference_fields(egg, oracle_mod):
                     assert mine[key] == ref[key], (step, w, key, mine[key], ref[key])
 
 
+def test_plain_c_caller_matches_the_oracle(egg, oracle_mod, tmp_path):
+    """tests/c/abi_roundtrip.c drives the library from C99 (no Python, no ctypes in the product path of that
+    process); its printed batch positions are the oracle's to the last digit"""
+    import subprocess
+    from test_abi import _build_c_caller
+    exe = _build_c_caller(tmp_path)
+    out = subprocess.run([exe, "7"], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "create 0"
+    o = oracle_mod.Oracle()
+    a = o.add(400.0, 300.0, 50.0, 15.0)
+    b = o.add(470.0, 320.0, 35.0, 9.0)
+    for k in range(7):
+        o.set_target_position(a, 400.0 + 3.0 * k, 300.0 - 2.0 * k)
+        o.update(1 / 60)
+    for line, i in zip(out[1:3], (a, b)):
+        _, bid, x, y = line.split()
+        assert int(bid) == i and (float(x), float(y)) == o.get_position(i), line
+    assert out[3].startswith("unknown id:") and "no batch with id" in out[3]
+
+
 def test_unsupported_configuration_fails_loudly(egg):
     """one collision pass per sub-step keeps a hash generation per sub-step alive; the device path holds 8"""
     h = egg.SimulationHandler()

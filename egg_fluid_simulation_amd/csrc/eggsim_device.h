@@ -82,7 +82,7 @@ static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_gr
     size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, l = (size_t)lcap, g = (size_t)(gens < 2 ? 2 : gens);
     size_t b = 0;
     b += 2 * egg_align16(n * 16);            // pos wr
-    b += 2 * egg_align16(nmax > threads ? n * 16 : 0);  // prev vel (registers otherwise)
+    b += 2 * egg_align16((nmax > threads || threads >= 3 * nmax) ? n * 16 : 0);  // prev vel (registers otherwise; wide tiles: LDS)
     b += 3 * egg_align16(a * 8);             // atx aty afd
     b += egg_align16(g * n * 4);             // ckey[gens]
     b += egg_align16(g * c * 4);             // cell[gens]

@@ -722,8 +722,14 @@ int retile(egg_handle *h, int which) {
             if (spread <= 0) spread = (lc.n_tiles <= h->prop.multiProcessorCount && !chip_shared) ? 3 : 1;
             const int wide_threads = egg_step_threads(lc.nmax, spread);
             if (spread > 1 && wide_threads <= 512 && wide_threads >= 3 * lc.nmax) {
-                threads = wide_threads;
-                lc.wide = 1;
+                // (a wide tile keeps velocities and sub-step start positions in LDS: the size depends on the thread count)
+                const size_t wide_lds = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0,
+                                                           wide_threads, 0, s.gens);
+                if (wide_lds <= h->lds_limit && wide_lds <= 64 * 1024) {
+                    threads = wide_threads;
+                    lc.wide = 1;
+                    lc.lds = wide_lds;
+                }
             }
             // room to spare (few tiles per CU): cache the position-independent terms of every pair
             const size_t with_cache = egg_step_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, lc.lcap, single ? 1 : 0, 0,

@@ -592,7 +592,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
     // projection (sixteen spinning waves against global memory outran a turn-count limit).  s_memrealtime
     // ticks at 100 MHz; it is read every 1024th turn, on the scalar unit.
     const unsigned long long t_start = wall_clock64();
-    const unsigned long long t_limit = 1000000000ull;  // 10 s for one pass of one tile
+    const unsigned int t_limit_2p24 = 60u;  // ~10 s for one pass of one tile, in units of 2^24 ticks of the 100 MHz clock
     (void)total;
     bool timed_out = false;
     for (int base = 0; base < per && !timed_out; ++base) {
@@ -686,7 +686,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
             }
             ++spins;
             if (__builtin_expect((spins & 1023u) == 0u, 0)) {
-                if (wall_clock64() - t_start > t_limit) {  // give up: no lane has a pending pair any more
+                if ((unsigned int)((wall_clock64() - t_start) >> 24) > t_limit_2p24) {  // give up: no lane has a pending pair any more
                     timed_out = true;
                     no_live = 0;
                 }
@@ -726,7 +726,7 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
         unsigned char *p = GLOBAL_STATE ? A.scratch + (size_t)tile * A.scratch_stride : smem;
         t.pos = (double2 *)carve(p, n * 16);
         t.wr = (double2 *)carve(p, n * 16);
-        const bool state_in_lds = A.nmax > nthreads;
+        const bool state_in_lds = WIDE || A.nmax > nthreads;
         t.prev = (double2 *)carve(p, state_in_lds ? n * 16 : 0);
         t.vel = (double2 *)carve(p, state_in_lds ? n * 16 : 0);
         t.atx = (double *)carve(p, a * 8);
@@ -854,7 +854,8 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
     // Velocity and sub-step start position are private to a particle.  With one thread per
     // particle (n <= threads) they stay in that thread's registers for the whole step; only tiles
     // with more particles than threads keep them in LDS.
-    const bool regs = n <= nthreads;
+    // (wide tiles have LDS to spare and registers to save: there the two live in LDS as well)
+    const bool regs = !WIDE && n <= nthreads;
     double2 rvel = make_double2(0.0, 0.0), rprev = rvel;
     auto global_index = [&](int i) {
         const int k = t.aslot[i];

@@ -109,3 +109,58 @@ def test_crowded_scene_on_a_shared_chip(egg, oracle_mod):
     # the run starts with more white tiles than CUs (narrow variants, one grid for all classes) and ends with
     # many islands merged
     assert max(tiles_seen) > 256 and min(tiles_seen) < n, (tiles_seen[0], tiles_seen[-1])
+
+
+CONFIG_CORNERS = [
+    dict(collision_strength=1.0),                       # compliance exactly 0
+    dict(collision_strength=0.0, follow_strength=0.0),  # softest constraints
+    dict(follow_strength=1.0, damping=1.0),             # velocities wiped every sub-step
+    dict(damping=0.0),                                  # nothing damped
+    dict(min_radius=4.0, max_radius=4.0, min_mass=2.0, max_mass=2.0),  # identical particles
+    dict(collision_overlap_factor=3.5),                 # larger cells through the overlap factor
+    dict(cohesion_interaction_distance_factor=5.0),     # cell size from the (dead) cohesion factor, L:1760
+    dict(max_radius=9.0, min_radius=1.0, max_mass=50.0),  # wide radius / mass spread
+]
+
+
+@pytest.mark.parametrize("tweak", CONFIG_CORNERS, ids=[",".join(sorted(t)) for t in CONFIG_CORNERS])
+def test_config_corners_match_oracle(egg, oracle_mod, tweak):
+    """solver configurations at and beyond the edges of the default file: every particle bit for bit"""
+    from egg_fluid_simulation_amd.default_config import default_configs
+    w, y = default_configs()
+    w.update(tweak)
+    y.update(tweak)
+    h = egg.SimulationHandler(w, y)
+    o = oracle_mod.Oracle()
+    o.set_config(WHITE, dict(oracle_mod.DEFAULT_WHITE, **tweak))
+    o.set_config(YOLK, dict(oracle_mod.DEFAULT_YOLK, **tweak))
+    cs = [(300.0, 300.0), (380.0, 330.0), (900.0, 100.0)]
+    for x, yy in cs:
+        h.add(x, yy, 50, 15)
+        o.add(x, yy, 50, 15)
+    for step in range(12):
+        for i, (x, yy) in enumerate(cs):
+            h.set_target_position(i + 1, x + 4.0 * step, yy - 3.0 * step)
+            o.set_target_position(i + 1, x + 4.0 * step, yy - 3.0 * step)
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+    _same(h, o, tweak)
+
+
+@pytest.mark.parametrize("radii", [(20.0, 9.0), (24.0, 12.0), (30.0, 9.0)])
+def test_budget_cuts_both_types(egg, oracle_mod, radii):
+    """one small blob: 0.05 N^2 is below the adjacent pairs of BOTH particle types, so passes of both are cut
+    by the budget return (L:1657-1658) and the stale passes look `collided` up in the cut lists"""
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    h.add(100.0, 100.0, *radii)
+    o.add(100.0, 100.0, *radii)
+    cut = {WHITE: False, YOLK: False}
+    for step in range(15):
+        h.set_target_position(1, 100.0 + 2.0 * step, 100.0 + 1.5 * step)
+        o.set_target_position(1, 100.0 + 2.0 * step, 100.0 + 1.5 * step)
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+        for s in o.pass_stats():
+            cut[s["which"]] = cut[s["which"]] or bool(s["cut"])
+    _same(h, o, radii)
+    assert cut[WHITE] and cut[YOLK], cut

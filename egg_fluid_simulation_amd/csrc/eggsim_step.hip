@@ -439,6 +439,7 @@ template <int MODE>  // as in enum_fresh_column
 __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_t *dst, int s0 = 0, int s1 = 9, int cap = 0) {
     const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.prev);
     const uint32_t kni = kn[i], koi = ko[i];
+    const bool settled = c.prev_uncut && kni == koi;
     int count = 0;
     for (int s = s0; s < s1; ++s) {
         const uint32_t nk = (uint32_t)((int)kni + (s / 3 - 1) * 65536 + (s % 3 - 1));
@@ -460,7 +461,10 @@ __device__ inline int enum_stale(const Tile &t, const PassCtx &c, int i, uint32_
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (e0 + q < cn && accept_stale(t, c, i, j[q], s, isnew, kni, koi, knj[q], koj[q])) {
+                    // (shortcut for the common case: neither particle changed its cell since the previous pass, so the
+                    // pair was adjacent then as well and -- that pass not being cut -- is in `collided`)
+                    if (e0 + q < cn && !(settled && knj[q] == koj[q]) &&
+                        accept_stale(t, c, i, j[q], s, isnew, kni, koi, knj[q], koj[q])) {
                         if (MODE == 1) {
                             dst[count] = (uint32_t)j[q] | ((uint32_t)i << 16);
                             atomicAdd(&t.done[j[q]], 1u);

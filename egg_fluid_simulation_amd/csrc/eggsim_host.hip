@@ -544,10 +544,6 @@ int retile(egg_handle *h, int which) {
                 s.swept |= side[q] > mk;
             }
             claim[k] = Box{b.lo_x - side[1], b.lo_y - side[3], b.hi_x + side[0], b.hi_y + side[2]};
-            static const bool debug_claims = getenv("EGG_DEBUG_CLAIMS") != nullptr;
-            if (debug_claims && k == 0)
-                fprintf(stderr, "[claims] type %d step %lld atom0: dist %.1f obs %d sides +x %d -x %d +y %d -y %d\n", which,
-                        (long long)h->stats.steps, dist, (int)have_motion, side[0], side[1], side[2], side[3]);
         }
         // union-find over atoms; candidate pairs by a sweep over lo_x
         std::vector<int> parent(na);

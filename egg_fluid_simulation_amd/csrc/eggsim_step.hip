@@ -644,9 +644,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
             // workgroup-scope acquire fence alone emits no wait on this target)
             if (GLOBAL_STATE) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#ifndef EGG_NO_GS_WAIT
                 __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             }
             const egg_d2 va = *p_pa, vb = *p_pb, vw = *p_wb;
             egg_d2 vc = {0.0, 0.0};
@@ -668,9 +666,7 @@ __device__ inline int execute_dataflow(const Tile &t, int cur, int n, int tid, i
                 *p_pb = (egg_d2){pb.x, pb.y};
                 EGG_COMPILER_BARRIER();  // data first, then the counters that publish it
                 if (GLOBAL_STATE) {  // positions acknowledged by memory before the counters announce them
-#ifndef EGG_NO_GS_WAIT
                     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 }
                 __hip_atomic_store(p_da, da + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

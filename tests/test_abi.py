@@ -133,3 +133,36 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     exe = _build_c_caller(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     assert out.splitlines()[0] in ("create -3", "create 0")  # -3 = EGG_ERR_NO_DEVICE on a box without a GPU
+
+
+def _prototypes(text):
+    """{name: normalised parameter-type list} of the `egg_*` prototypes in a piece of C"""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|void|const char \*)\s*(egg_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", text):
+        params = []
+        for prm in m.group(2).split(","):
+            prm = " ".join(prm.split())
+            prm = re.sub(r"\b[a-zA-Z_][a-zA-Z_0-9]*$", "", prm).strip()  # drop the parameter name
+            params.append(prm.replace(" *", "*"))
+        out[m.group(1)] = params
+    return out
+
+
+def test_lua_binding_declares_the_header_prototypes():
+    """the LuaJIT wrapper cannot run here, but its ffi.cdef block can be held against include/eggsim.h: every
+    function it binds must have exactly the header's parameter types"""
+    lua = open(os.path.join(ROOT, "egg_fluid_simulation_amd", "lua", "egg_fluid_simulation", "simulation_handler.lua")).read()
+    cdef = re.search(r"ffi\.cdef\[\[(.*?)\]\]", lua, flags=re.S).group(1)
+    header = _prototypes(open(os.path.join(ROOT, "include", "eggsim.h")).read())
+    bound = _prototypes(cdef)
+    assert len(bound) >= 12
+    for name, params in bound.items():
+        assert name in header, name
+        assert params == header[name], (name, params, header[name])
+    # and the two structs it passes by pointer have the header's field order
+    for struct in ("egg_config", "egg_environment"):
+        def fields(text):
+            body = re.search(r"typedef struct\s*\{([^}]*)\}\s*" + struct + r"\s*;", re.sub(r"/\*.*?\*/", " ", text, flags=re.S), flags=re.S).group(1)
+            return re.findall(r"[a-z_]+(?=\s*[,;])", body)
+        assert fields(cdef) == fields(open(os.path.join(ROOT, "include", "eggsim.h")).read()), struct

@@ -23,6 +23,7 @@ EGG_ERR_UNSUPPORTED = -5
 EGG_ERR_INTERNAL = -6
 
 WHITE, YOLK = 0, 1
+DEFAULT_COUNT = -1  # EGG_DEFAULT_COUNT: the caller gave nil for a particle count
 
 FIELDS = ["x", "y", "vx", "vy", "last_x", "last_y", "radius", "inv_mass", "mass_t", "batch_id"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}

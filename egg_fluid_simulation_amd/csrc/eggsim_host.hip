@@ -241,6 +241,13 @@ int fail(egg_handle *h, int code, const char *fmt, ...) {
     return code;
 }
 
+// state-mutating entry points are refused between egg_step_begin and egg_step_end: the launched step reads the
+// arrays and tiles they would change, and egg_step_end validates / commits exactly what was launched
+#define REJECT_IN_FLIGHT(h, name)                                                                      \
+    do {                                                                                               \
+        if ((h)->in_flight) return fail(h, EGG_ERR_INVALID_ARGUMENT, name ": a step is in flight (egg_step_begin without egg_step_end)"); \
+    } while (0)
+
 #define HIP_TRY(h, expr)                                                                               \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -1048,6 +1055,9 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                                s.stream, s.mass_t.p, s.inv_mass.p, s.radius.p, (int)s.n, upd_mass ? 1 : 0,
                                s.cfg.min_mass, s.cfg.max_mass, upd_radius ? 1 : 0, s.cfg.min_radius, s.cfg.max_radius);
             HIP_TRY(h, hipGetLastError());
+            // the step that reads these arrays may be launched on the OTHER type's stream (one fused launch
+            // for both types): finish here -- config changes are rare, the wait costs nothing that matters
+            HIP_TRY(h, hipStreamSynchronize(s.stream));
             h->stats.kernel_launches++;
         }
         s.has_env = true;
@@ -1373,6 +1383,7 @@ void egg_destroy(egg_handle *h) {
 int egg_set_config(egg_handle *h, int which, const egg_config *cfg) {
     if (!h || !cfg || (which != EGG_WHITE && which != EGG_YOLK)) return EGG_ERR_INVALID_ARGUMENT;
     if (!(cfg->eps >= 0x1p-300 && cfg->eps <= 1.0)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_config.eps must be in [2^-300, 1]");
+    REJECT_IN_FLIGHT(h, "egg_set_config");
     h->sys[which].cfg = *cfg;
     return EGG_OK;
 }
@@ -1408,6 +1419,7 @@ int egg_add_many_keyed(egg_handle *h, int64_t n, const double *xs, const double 
 static int add_many_impl(egg_handle *h, int64_t n, const double *xs, const double *ys, double white_radius,
                          double yolk_radius, int64_t white_n, int64_t yolk_n, const int64_t *keys, int64_t *out_ids) {
     if (!h || n < 0 || (n > 0 && (!xs || !ys))) return EGG_ERR_INVALID_ARGUMENT;
+    REJECT_IN_FLIGHT(h, "egg_add");
     (void)hipSetDevice(h->device);
     const egg_config &wc = h->sys[0].cfg, &yc = h->sys[1].cfg;
     // L:33-58
@@ -1415,10 +1427,11 @@ static int add_many_impl(egg_handle *h, int64_t n, const double *xs, const doubl
     double yolk_particle_radius = mixd(yc.min_radius, yc.max_radius, 0.5);
     if (std::isnan(white_radius)) white_radius = white_particle_radius * 15;
     if (std::isnan(yolk_radius)) yolk_radius = white_radius * (10.0 / 50);
-    if (white_n <= 0)
+    // only the sentinel means "not given" (L:52-58); an explicit 0 or negative count reaches the `<= 1` check below
+    if (white_n == EGG_DEFAULT_COUNT)
         white_n = (int64_t)std::ceil((kPi * (white_radius * white_radius)) /
                                      (kPi * (white_particle_radius * white_particle_radius)));
-    if (yolk_n <= 0)
+    if (yolk_n == EGG_DEFAULT_COUNT)
         yolk_n = (int64_t)std::ceil((kPi * (yolk_radius * yolk_radius)) /
                                     (kPi * (yolk_particle_radius * yolk_particle_radius)));
     // L:71-85
@@ -1474,6 +1487,7 @@ int egg_add(egg_handle *h, double x, double y, double white_radius, double yolk_
 
 int egg_remove(egg_handle *h, int64_t id) {  // L:140-155, L:1037-1106
     if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    REJECT_IN_FLIGHT(h, "egg_remove");
     Batch *b = find_batch(h, id);
     if (!b) return fail(h, EGG_WARN_UNKNOWN_ID, "In SimulationHandler.remove: no batch with id `%lld`", (long long)id);
     (void)hipSetDevice(h->device);
@@ -1511,6 +1525,7 @@ int egg_remove(egg_handle *h, int64_t id) {  // L:140-155, L:1037-1106
 
 int egg_set_target(egg_handle *h, int64_t id, double x, double y) {  // L:254-264
     if (!h) return EGG_ERR_INVALID_ARGUMENT;
+    REJECT_IN_FLIGHT(h, "egg_set_target");
     Batch *b = find_batch(h, id);
     if (!b)
         return fail(h, EGG_WARN_UNKNOWN_ID, "In SimulationHandler.set_target_position: no batch with id `%lld`",
@@ -1552,6 +1567,7 @@ int egg_step(egg_handle *h, double delta, int32_t n_substeps, int32_t n_collisio
     if (!h) return EGG_ERR_INVALID_ARGUMENT;
     if (n_substeps < 1 || n_collision_steps < 1 || std::isnan(delta))
         return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_step: invalid arguments");
+    REJECT_IN_FLIGHT(h, "egg_step");
     (void)hipSetDevice(h->device);
     return do_step(h, delta, n_substeps, n_collision_steps);
 }
@@ -1560,6 +1576,7 @@ int egg_update(egg_handle *h, double delta, double step_delta, int32_t n_substep
                int32_t *out_n_steps) {  // L:168-222
     if (!h) return EGG_ERR_INVALID_ARGUMENT;
     if (out_n_steps) *out_n_steps = 0;
+    REJECT_IN_FLIGHT(h, "egg_update");
     if (std::isnan(delta)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.update: `delta` is not a number");
     if (step_delta < 0 || std::isnan(step_delta))
         return fail(h, EGG_ERR_INVALID_ARGUMENT, "In SimulationHandler.update: `step_delta` is not a number > 0");
@@ -1591,6 +1608,7 @@ int egg_update(egg_handle *h, double delta, double step_delta, int32_t n_substep
 
 int egg_prepare_step(egg_handle *h, double step_delta, int32_t n_substeps, int32_t n_collision_steps) {
     if (!h || n_substeps < 1 || n_collision_steps < 1 || !(step_delta >= 0)) return EGG_ERR_INVALID_ARGUMENT;
+    REJECT_IN_FLIGHT(h, "egg_prepare_step");
     (void)hipSetDevice(h->device);
     return do_step(h, step_delta, n_substeps, n_collision_steps, kPrepare);
 }
@@ -1694,6 +1712,8 @@ int egg_get_bounds_many(egg_handle *h, int64_t n, const int64_t *ids, double *lo
         if (rc != EGG_OK) return rc;
         cell[w] = cell_size_of(s.cfg);
         const size_t na = s.atoms.size();
+        if (h->in_flight && !s.aabb_valid && na)  // the running step kernel owns the device-side box buffer
+            return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_get_bounds_many: cell boxes are not available while a step is in flight");
         if (!s.aabb_valid && s.aabb_on_device && s.tiled_cell_size == cell[w]) {
             rc = fetch_end_aabb(h, s);
             if (rc != EGG_OK) return rc;
@@ -1865,6 +1885,7 @@ int egg_import_batch(egg_handle *h, const egg_batch_info *info, const double *wh
                      int64_t *out_id) {
     if (!h || !info || !white_state || !yolk_state || info->n_white < 1 || info->n_yolk < 1)
         return EGG_ERR_INVALID_ARGUMENT;
+    REJECT_IN_FLIGHT(h, "egg_import_batch");
     (void)hipSetDevice(h->device);
     // position in the layout order
     size_t pos = 0;

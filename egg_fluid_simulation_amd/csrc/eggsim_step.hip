@@ -79,7 +79,7 @@ struct Tile {
                           //               distance): the position-independent part of the projection, computed
                           //               by all lanes when the lists are ranked instead of by the serial scheduler
     int32_t *aclaim, *aoff, *abatch, *aglob, *aaabb, *adisp;
-    int32_t *sc;  // scalars: 2 particle count; 3 origin x; 4 origin y; 5 misc; 6 gw; 7 gh; 8.. scan carries
+    int32_t *sc;  // scalars: 2 particle count; 3 origin x; 4 origin y; 5 misc; 6 gw; 7 gh; 10 cut history; 11 mass-guard pairs of the pass
     uint16_t *hitems_b;   // [2][nmax]     particles sorted by cell, ascending index inside a cell
     uint16_t *pslot, *aslot, *nlo;
     uint16_t *own_ent_b;  // [2][lcap]     exact-budget mode only: plain copies of this and the previous pass's lists
@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
                 for (int e = tid; e < total; e += nthreads) t.own_ent(cur)[e] = (uint16_t)t.own_pack[e];
             }
             if (tid == 0) {
-                atomicAdd(&A.status->visits[min(pass_seq, EGG_MAX_PASSES - 1)], (unsigned long long)total);
+                t.sc[11] = 0;  // pairs of this pass that fail the mass guard (counted by the rank pass below)
                 if (this_cut) atomicExch(&A.status->was_cut, 1);
             }
 
@@ -1208,6 +1208,8 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
                 // bit 15: this pair must take the reference path (position-independent part of the test)
                 const uint32_t slow = pair_needs_reference(t.wr[cself], t.wr[i], A.overlap_factor, A.collision_compliance, eps)
                                           ? 0x8000u : 0u;
+                // a pair failing the mass guard (L:1601) is marked in `collided` but leaves n_collided alone
+                if (slow && t.wr[cself].x + t.wr[i].x < eps) atomicAdd(&t.sc[11], 1);
                 t.own_pack[e] = (uint32_t)i | slow | (rank << 16);
                 if (t.pinv) {
                     const double2 ws = t.wr[cself], wo = t.wr[i];
@@ -1227,6 +1229,8 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
                 t.nlo[i] = (uint16_t)nl;
             }
             __syncthreads();
+            if (tid == 0)  // n_collided of this pass (L:1657): the visited pairs that passed the mass guard
+                atomicAdd(&A.status->visits[min(pass_seq, EGG_MAX_PASSES - 1)], (unsigned long long)(total - t.sc[11]));
 
             PROF(6)  // transpose
             // -------------------------------------- dataflow execution of the pair projections

@@ -46,6 +46,7 @@ int egg_get_environment(egg_handle *h, int which, egg_environment *out);
 
 local lib = ffi.load(os.getenv("EGGSIM_LIB") or "eggsim")
 local NaN = 0 / 0
+local EGG_DEFAULT_COUNT = -1 -- include/eggsim.h
 
 local SimulationHandler = {}
 setmetatable(SimulationHandler, { __call = function(_, ...) return SimulationHandler.new(...) end })
@@ -131,6 +132,7 @@ function SimulationHandler.new(white_config, yolk_config, device)
     self._white_config, self._yolk_config = {}, {}
     self._mass_distribution_variance = 4
     self._max_collision_fraction = 0.05
+    self._batch_colors = {} -- render attribute, host side only (simulation_handler.lua:297-395)
     self:_load_config(_deepcopy(white_config), true)
     self:_load_config(_deepcopy(yolk_config), false)
     local out = ffi.new("egg_handle*[1]")
@@ -141,16 +143,58 @@ function SimulationHandler.new(white_config, yolk_config, device)
 end
 
 function SimulationHandler:add(x, y, white_radius, yolk_radius, white_color, yolk_color, white_n_particles, yolk_n_particles)
+    -- argument handling of the reference's add (simulation_handler.lua:27-120), in its order: defaults, type
+    -- assertion, radius / count errors, colour errors and warnings; the particle-count defaults themselves
+    -- are computed by the library (EGG_DEFAULT_COUNT = "the caller gave nil"), from the same formula (L:52-58)
+    white_color = white_color or self._white_config.color
+    yolk_color = yolk_color or self._yolk_config.color
     log.assert(x, "number", y, "number")
+    if white_radius ~= nil then log.assert(white_radius, "number") end
+    if yolk_radius ~= nil then log.assert(yolk_radius, "number") end
+    log.assert(white_color, "table", yolk_color, "table")
+    if white_n_particles ~= nil then log.assert(white_n_particles, "number") end
+    if yolk_n_particles ~= nil then log.assert(yolk_n_particles, "number") end
+
+    if white_radius ~= nil and white_radius <= 0 then
+        log.error("In SimulationHandler.add: white radius cannot be 0 or negative")
+    end
+    if yolk_radius ~= nil and yolk_radius <= 0 then
+        log.error("In SimulationHandler.add: yolk radius cannot be 0 or negative")
+    end
+    if white_n_particles ~= nil and white_n_particles <= 1 then
+        log.error("In SimulationHandler.add: white particle count cannot be 1 or negative")
+    end
+    if yolk_n_particles ~= nil and yolk_n_particles <= 1 then
+        log.error("In SimulationHandler.add: yolk particle count cannot be 1 or negative")
+    end
+
+    local component_names = { "r", "g", "b", "a" }
+    for _, entry in ipairs({ { "white", white_color }, { "yolk", yolk_color } }) do
+        local name, color = entry[1], entry[2]
+        for i, component_name in ipairs(component_names) do
+            if type(color[i]) ~= "number" or math.is_nan(color[i]) then
+                log.error("In SimulationHandler.add: ", name, " color component `", component_name, "` is not a number")
+                return
+            end
+            if color[i] < 0 or color[i] > 1 then
+                log.warning("In SimulationHandler.add: ", name, " color component `", component_name, "` is outside of [0, 1]")
+            end
+            color[i] = math.clamp(color[i], 0, 1)
+        end
+    end
+
     local id = ffi.new("int64_t[1]")
+    -- status 2 (EGG_WARN_FEW_PARTICLES) carries the reference's "only `n` particles will be created" warning
     self:_check(lib.egg_add(self._h, x, y, white_radius or NaN, yolk_radius or NaN,
-        white_n_particles and math.ceil(white_n_particles) or 0, yolk_n_particles and math.ceil(yolk_n_particles) or 0, id))
+        white_n_particles and math.ceil(white_n_particles) or EGG_DEFAULT_COUNT,
+        yolk_n_particles and math.ceil(yolk_n_particles) or EGG_DEFAULT_COUNT, id))
+    self._batch_colors[tonumber(id[0])] = { white_color, yolk_color }
     return tonumber(id[0])
 end
 
 function SimulationHandler:remove(batch_id)
     log.assert(batch_id, "number")
-    self:_check(lib.egg_remove(self._h, batch_id))
+    if self:_check(lib.egg_remove(self._h, batch_id)) == 0 then self._batch_colors[batch_id] = nil end
 end
 
 function SimulationHandler:update(delta, step_delta, n_substeps, n_collision_steps)

@@ -202,6 +202,16 @@ class SimulationHandler:
             if v is not None:
                 _assert_types(v, "number")
         _assert_types(white_color, "table", yolk_color, "table")
+        # L:71-85 come before the colour checks in the reference; nothing may be created when they fail, so they
+        # are made here before the C call (the library repeats them: only EGG_DEFAULT_COUNT means "not given")
+        if white_radius is not None and white_radius <= 0:
+            raise EggError("[ERROR] In SimulationHandler.add: white radius cannot be 0 or negative")
+        if yolk_radius is not None and yolk_radius <= 0:
+            raise EggError("[ERROR] In SimulationHandler.add: yolk radius cannot be 0 or negative")
+        if white_n_particles is not None and white_n_particles <= 1:
+            raise EggError("[ERROR] In SimulationHandler.add: white particle count cannot be 1 or negative")
+        if yolk_n_particles is not None and yolk_n_particles <= 1:
+            raise EggError("[ERROR] In SimulationHandler.add: yolk particle count cannot be 1 or negative")
         for name, color in (("white", white_color), ("yolk", yolk_color)):  # L:87-108
             for i, cname in enumerate("rgba"):
                 if i >= len(color) or _type_name(color[i]) != "number" or _is_nan(color[i]):
@@ -214,13 +224,9 @@ class SimulationHandler:
         rc = self._lib.egg_add(self._h, float(x), float(y),
                                float("nan") if white_radius is None else float(white_radius),
                                float("nan") if yolk_radius is None else float(yolk_radius),
-                               0 if white_n_particles is None else int(math.ceil(white_n_particles)),
-                               0 if yolk_n_particles is None else int(math.ceil(yolk_n_particles)),
+                               _ffi.DEFAULT_COUNT if white_n_particles is None else int(math.ceil(white_n_particles)),
+                               _ffi.DEFAULT_COUNT if yolk_n_particles is None else int(math.ceil(yolk_n_particles)),
                                C.byref(out))
-        if white_n_particles is not None and white_n_particles <= 1:
-            raise EggError("[ERROR] In SimulationHandler.add: white particle count cannot be 1 or negative")
-        if yolk_n_particles is not None and yolk_n_particles <= 1:
-            raise EggError("[ERROR] In SimulationHandler.add: yolk particle count cannot be 1 or negative")
         self._check(rc)
         self._batch_colors[out.value] = ([min(max(c, 0), 1) for c in white_color[:4]],
                                          [min(max(c, 0), 1) for c in yolk_color[:4]])
@@ -238,8 +244,8 @@ class SimulationHandler:
             self._h, xs.shape[0], xs.ctypes.data, ys.ctypes.data,
             float("nan") if white_radius is None else float(white_radius),
             float("nan") if yolk_radius is None else float(yolk_radius),
-            0 if white_n_particles is None else int(white_n_particles),
-            0 if yolk_n_particles is None else int(yolk_n_particles), ids.ctypes.data))
+            _ffi.DEFAULT_COUNT if white_n_particles is None else int(white_n_particles),
+            _ffi.DEFAULT_COUNT if yolk_n_particles is None else int(yolk_n_particles), ids.ctypes.data))
         return ids
 
     def add_many_keyed(self, xs, ys, keys, white_radius=None, yolk_radius=None):
@@ -251,7 +257,8 @@ class SimulationHandler:
         self._check(self._lib.egg_add_many_keyed(
             self._h, xs.shape[0], xs.ctypes.data, ys.ctypes.data,
             float("nan") if white_radius is None else float(white_radius),
-            float("nan") if yolk_radius is None else float(yolk_radius), 0, 0, keys.ctypes.data, ids.ctypes.data))
+            float("nan") if yolk_radius is None else float(yolk_radius), _ffi.DEFAULT_COUNT, _ffi.DEFAULT_COUNT,
+            keys.ctypes.data, ids.ctypes.data))
         return ids
 
     def export_batch(self, batch_id):

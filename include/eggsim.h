@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EGGSIM_ABI_VERSION 1
+#define EGGSIM_ABI_VERSION 2
 
 typedef struct egg_handle egg_handle;
 
@@ -81,8 +81,11 @@ int egg_set_config(egg_handle *h, int which, const egg_config *cfg);
 int egg_get_config(const egg_handle *h, int which, egg_config *cfg);
 
 /* add(x, y, white_radius, yolk_radius, ..., white_n, yolk_n) -> id (L:27-135).
- * Pass NaN for a radius and <= 0 for a count to get the reference's defaults
- * (L:41-58).  Colors are render attributes and stay on the host side. */
+ * Pass NaN for a radius and EGG_DEFAULT_COUNT for a count where the caller gave nil: the reference's
+ * defaults apply (L:41-58).  Any other count <= 1 -- an explicit 0 or negative one included -- is the
+ * reference's "particle count cannot be 1 or negative" error (L:79-85) and creates nothing.
+ * Colors are render attributes and stay on the host side. */
+#define EGG_DEFAULT_COUNT ((int64_t)-1)
 int egg_add(egg_handle *h, double x, double y, double white_radius, double yolk_radius,
             int64_t white_n, int64_t yolk_n, int64_t *out_id);
 /* n batches with identical radii in one call (bulk form for 10^4..10^5 batches) */

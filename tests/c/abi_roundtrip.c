@@ -15,7 +15,7 @@ int main(int argc, char **argv) {
     printf("create %d\n", rc);
     if (rc != EGG_OK) return rc == EGG_ERR_NO_DEVICE ? 0 : 1;
     int64_t a = 0, b = 0;
-    if (egg_add(h, 400.0, 300.0, 50.0, 15.0, 0, 0, &a) < 0 || egg_add(h, 470.0, 320.0, 35.0, 9.0, 0, 0, &b) < 0) {
+    if (egg_add(h, 400.0, 300.0, 50.0, 15.0, EGG_DEFAULT_COUNT, EGG_DEFAULT_COUNT, &a) < 0 || egg_add(h, 470.0, 320.0, 35.0, 9.0, EGG_DEFAULT_COUNT, EGG_DEFAULT_COUNT, &b) < 0) {
         fprintf(stderr, "add failed: %s\n", egg_last_error(h));
         return 1;
     }

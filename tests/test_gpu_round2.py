@@ -1,0 +1,229 @@
+"""Round-2 parity cases of the device path (through the C ABI) against the CPU oracle:
+  * BASELINE configs 4 and 5 at full size on one GPU (sampled-island parity, determinism, tiling);
+  * the mass guard of the pair loop (simulation_handler.lua:1601) and what `n_collided` counts there;
+  * particles closer than math.eps (math.lua:53-56: normalize returns (0, 0));
+  * a yolk-only mass change between two fused launches (L:1420-1430, L:1731-1744);
+  * the boundary's refusals: explicit particle counts <= 1 create nothing (L:79-85), state-changing calls
+    between egg_step_begin and egg_step_end are rejected.
+Everything is compared bit for bit; the north star's 1e-4 relative tolerance is therefore met with zero difference."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WHITE, YOLK = 0, 1
+N_W, N_Y = 157, 15  # particles per batch at white r = 50, yolk r = 15, particle r = 4 (L:52-58)
+
+
+@pytest.fixture(scope="module")
+def egg():
+    import egg_fluid_simulation_amd as e
+    return e
+
+
+def _same(h, o, tag):
+    for w in (WHITE, YOLK):
+        for f in ("x", "y", "vx", "vy"):
+            a, b = h.download(w, f), o.field(w, f)
+            assert a.shape == b.shape and np.array_equal(a, b), (tag, w, f)
+    assert h.stats()["pair_solves"] == o.total_visited, tag
+
+
+def _grid_xy(side, pitch=160.0, x0=100.0):
+    k = np.arange(side * side)
+    return x0 + pitch * (k % side), x0 + pitch * (k // side)
+
+
+def _full_size_config(egg, oracle_mod, side, steps, n_sample, seed):
+    """`side` x `side` non-overlapping batches (BASELINE config 4: 128, config 5: 256) on ONE GPU.
+    Non-overlapping batches are independent islands and the budget 0.05 N^2 is far from binding, so an
+    oracle that holds only a SAMPLE of the batches, at the same coordinates and in the same order, must
+    reproduce exactly those batches' particles (the sequential oracle cannot run 11 M particles in a test)."""
+    xs, ys = _grid_xy(side)
+    n = side * side
+    rng = np.random.default_rng(seed)
+    sample = np.unique(np.concatenate([[0, side - 1, n - side, n - 1, n // 2 + side // 2],
+                                       rng.choice(n, n_sample, replace=False)]))
+    h = egg.SimulationHandler()
+    ids = h.add_many(xs, ys, 50, 15)
+    o = oracle_mod.Oracle()
+    for k in sample:
+        o.add(float(xs[k]), float(ys[k]), 50, 15)
+    # every target translates by the same small vector per step (the gate-B motion at reduced amplitude:
+    # islands must stay apart at the 160 px pitch)
+    for step in range(steps):
+        dx, dy = 3.0 * (step + 1), -2.0 * (step + 1)
+        h.set_target_positions(ids, xs + dx, ys + dy)
+        for j, k in enumerate(sample):
+            o.set_target_position(j + 1, float(xs[k] + dx), float(ys[k] + dy))
+        assert h.update(1 / 60) == 1
+        o.update(1 / 60)
+    st = h.stats()
+    assert st["n_tiles"][WHITE] == n and st["redo_steps"] == 0, st
+    assert st["single_tile"] == [0, 0]
+    assert h.get_n_particles() == (n * N_W, n * N_Y)
+    state = {}
+    for w, per in ((WHITE, N_W), (YOLK, N_Y)):
+        for f in ("x", "y", "vx", "vy"):
+            dev = h.download(w, f)
+            state[(w, f)] = dev
+            got = dev.reshape(n, per)[sample].ravel()
+            assert np.array_equal(got, o.field(w, f)), (side, w, f)
+    # visited pairs: the sampled islands' share of the device total is what the oracle counted for them
+    gx, gy = h.get_positions(ids[sample])
+    ref = np.array([o.get_position(j + 1) for j in range(len(sample))])
+    assert np.array_equal(gx, ref[:, 0]) and np.array_equal(gy, ref[:, 1])
+    return h, state, (xs, ys, ids)
+
+
+def test_config4_16384_batches_full_size(egg, oracle_mod):
+    h, state, (xs, ys, _) = _full_size_config(egg, oracle_mod, 128, 3, 16, seed=4)
+    # identical islands at different places: all 16,384 visit the same number of pairs per step
+    per_batch = h.stats()["pair_solves"] / 16384
+    assert per_batch == int(per_batch)
+    # determinism: a second handler (16,384 independently scheduled tiles) reproduces every bit
+    h2 = egg.SimulationHandler()
+    ids2 = h2.add_many(xs, ys, 50, 15)
+    for step in range(3):
+        h2.set_target_positions(ids2, xs + 3.0 * (step + 1), ys - 2.0 * (step + 1))
+        h2.update(1 / 60)
+    for (w, f), a in state.items():
+        assert np.array_equal(h2.download(w, f), a), (w, f)
+    assert h2.stats()["pair_solves"] == h.stats()["pair_solves"]
+
+
+def test_config5_65536_batches_full_size(egg, oracle_mod):
+    h, state, _ = _full_size_config(egg, oracle_mod, 256, 2, 16, seed=5)
+    assert h.get_n_particles() == (65536 * N_W, 65536 * N_Y)  # 11,272,192 particles on one GPU
+    # every particle finite and within reach of its batch's target
+    x = state[(WHITE, "x")].reshape(65536, N_W)
+    assert np.isfinite(x).all() and np.isfinite(state[(WHITE, "vy")]).all()
+
+
+MASS_TWEAKS = [
+    dict(max_mass=1e9),                 # inverse masses 1e-9 .. 1.7e-8: the guard w_i + w_j < 1e-8 splits the pairs
+    dict(min_mass=3e8, max_mass=1e9),   # every pair fails the guard; no particle follows (w <= eps, L:1458)
+    dict(min_mass=1.0, max_mass=2.0e8 / 0.9),  # only the few heaviest pairs (mass_t near 1) are guarded
+]
+
+
+@pytest.mark.parametrize("tweak", MASS_TWEAKS, ids=["mixed", "all_guarded", "few_guarded"])
+@pytest.mark.parametrize("centers", [[(300.0, 300.0)], [(300.0, 300.0), (340.0, 320.0), (300.0, 350.0)],
+                                     [(100.0 + 90.0 * k, 100.0 + 35.0 * (k % 3)) for k in range(12)]],
+                         ids=["one_batch_exact_budget", "three_overlapping", "twelve_tiles"])
+def test_mass_guard_pairs_match_oracle(egg, oracle_mod, tweak, centers):
+    """L:1601: a pair whose inverse masses add up to less than eps is marked in `collided` but neither
+    projected nor counted in n_collided -- so it does not use up budget either (one batch: the yolk budget of
+    12 pairs per pass binds, L:1657)"""
+    from egg_fluid_simulation_amd.default_config import default_configs
+    w, y = default_configs()
+    w.update(tweak)
+    y.update(tweak)
+    h = egg.SimulationHandler(w, y)
+    o = oracle_mod.Oracle()
+    o.set_config(WHITE, dict(oracle_mod.DEFAULT_WHITE, **tweak))
+    o.set_config(YOLK, dict(oracle_mod.DEFAULT_YOLK, **tweak))
+    for cx, cy in centers:
+        assert h.add(cx, cy, 50, 15) == o.add(cx, cy, 50, 15)
+    guarded = 0
+    for step in range(8):
+        for i, (cx, cy) in enumerate(centers):
+            h.set_target_position(i + 1, cx + 5.0 * step, cy + 3.0 * step)
+            o.set_target_position(i + 1, cx + 5.0 * step, cy + 3.0 * step)
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+        _same(h, o, (tweak, step))
+    inv = o.field(WHITE, "inv_mass")
+    guarded = int((inv[:, None] + inv[None, :] < 1e-8).sum())
+    assert guarded > 0  # the case does reach the guard
+
+
+def test_particles_closer_than_eps(egg, oracle_mod):
+    """sub-eps distances through the device path: coincident twins of two batches on one centre (different
+    batches: collision only), and a batch so small that all its particles lie within 1e-9 of each other
+    (same batch: the dead cohesion block fires on exact coincidence, the collision's normalize() returns
+    (0, 0) below eps, math.lua:53-56)"""
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # "only 2 white / 2 yolk particles will be created"
+        for x, y, wr, yr, wn, yn in ((0.0, 0.0, 40.0, 40.0, 2, 2), (0.0, 0.0, 40.0, 40.0, 2, 2),
+                                     (200.0, 50.0, 1e-9, 1e-9, 12, 6), (-70.0, -35.0, 50.0, 15.0, 157, 15)):
+            assert h.add(x, y, wr, yr, None, None, wn, yn) == o.add(x, y, wr, yr, wn, yn)
+    for step in range(6):
+        for i in (1, 2, 3, 4):
+            tx, ty = 3.0 * step * (i - 2), 2.0 * step
+            h.set_target_position(i, tx, ty)
+            o.set_target_position(i, tx, ty)
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+        _same(h, o, step)
+    x, y = h.download(WHITE, "x"), h.download(WHITE, "y")
+    assert x[0] == x[2] and y[0] == y[2] and x[1] == x[3] and y[1] == y[3]  # coincident twins never separate
+
+
+def test_yolk_only_mass_change_between_fused_launches(egg, oracle_mod):
+    """A yolk min/max mass change keeps the cell size, so no re-tiling (and none of its stream syncs) happens
+    between the re-derivation kernel (L:1420-1430) and the next step -- which runs the yolk tiles inside the
+    launch on the white stream.  The new inverse masses must be what that launch reads."""
+    from egg_fluid_simulation_amd.default_config import default_configs
+    n = 300
+    xs = 100.0 + 160.0 * (np.arange(n) % 20)
+    ys = 100.0 + 160.0 * (np.arange(n) // 20)
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    ids = h.add_many(xs, ys, 50, 15)
+    for a, b in zip(xs, ys):
+        o.add(float(a), float(b), 50, 15)
+    for step in range(6):
+        if step in (2, 4):
+            tweak = dict(min_mass=0.5 + step, max_mass=3.0 * step)
+            w, y = default_configs()
+            y.update(tweak)
+            h.set_yolk_config(y)
+            o.set_config(YOLK, dict(oracle_mod.DEFAULT_YOLK, **tweak))
+        h.set_target_positions(ids, xs + 2.0 * step, ys + 1.0 * step)
+        for i, a, b in zip(ids, xs, ys):
+            o.set_target_position(int(i), float(a + 2.0 * step), float(b + 1.0 * step))
+        retiles = h.stats()["retiles"]
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+        assert h.stats()["fused_launch"] == 1
+        _same(h, o, step)
+        assert np.array_equal(h.download(YOLK, "inv_mass"), o.field(YOLK, "inv_mass"))
+    del retiles
+
+
+def test_explicit_small_counts_create_nothing(egg):
+    """L:79-85: a count <= 1 throws before anything is created; only nil means 'use the default'"""
+    h = egg.SimulationHandler()
+    a = h.add(0, 0, 50, 15)
+    for bad in (0, 1, -3):
+        with pytest.raises(egg.EggError, match="white particle count cannot be 1 or negative"):
+            h.add(10, 10, 50, 15, None, None, bad, 15)
+        with pytest.raises(egg.EggError, match="yolk particle count cannot be 1 or negative"):
+            h.add(10, 10, 50, 15, None, None, 157, bad)
+    assert h.list_ids() == [a] and h.get_n_particles() == (N_W, N_Y)
+    assert h.add(10, 10, 50, 15) == a + 1  # no id was consumed by the refused calls
+    # the C entry point itself refuses an explicit 0 (the wrapper's check is not the only one)
+    import ctypes as C
+    from egg_fluid_simulation_amd import _ffi
+    out = C.c_int64()
+    rc = h._lib.egg_add(h._h, 0.0, 0.0, 50.0, 15.0, 0, _ffi.DEFAULT_COUNT, C.byref(out))
+    assert rc == _ffi.EGG_ERR_INVALID_ARGUMENT and h.list_ids() == [a, a + 1]
+
+
+def test_state_changes_are_refused_while_a_step_is_in_flight(egg, oracle_mod):
+    h, o = egg.SimulationHandler(), oracle_mod.Oracle()
+    for s in (h, o):
+        s.add(100.0, 100.0, 50, 15)
+        s.add(400.0, 100.0, 50, 15)
+    h.step_begin(1 / 60, 2, 3)
+    for call in (lambda: h.add(700.0, 100.0, 50, 15), lambda: h.remove(1), lambda: h.step(1 / 60, 2, 3),
+                 lambda: h.update(1 / 60), lambda: h.set_target_position(1, 5.0, 5.0),
+                 lambda: h.set_white_config(h.get_white_config()), lambda: h.step_begin(1 / 60, 2, 3)):
+        with pytest.raises(egg.EggError, match="in flight"):
+            call()
+    h.step_end(True)
+    o.step(1 / 60, 2, 3)
+    _same(h, o, "after the refused calls")
+    assert h.list_ids() == [1, 2]

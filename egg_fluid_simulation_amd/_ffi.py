@@ -38,6 +38,8 @@ OPT_BUDGET_PARTICLES_WHITE = 6
 OPT_BUDGET_PARTICLES_YOLK = 7
 OPT_FORCE_GLOBAL_STATE = 8
 OPT_FUSE_TYPES = 9
+OPT_PACKED = 10
+OPT_GROUP_PARTICLES = 11
 
 CONFIG_FIELDS = ["damping", "follow_strength", "cohesion_strength",
                  "cohesion_interaction_distance_factor", "collision_strength",

@@ -14,7 +14,8 @@ struct EggStatus {
     int32_t fail_range;     // a cell coordinate does not fit the packed tile-relative form
     int32_t min_slack;      // min over particles of the distance (cells) to their claim box edge at step end
     int32_t was_cut;        // single-tile mode: the collision budget cut some pass (L:1657-1658)
-    int32_t pad0, pad1;
+    int32_t fail_levels;    // packed pipeline: a group's pair-dependency DAG is deeper than the level table of the launch
+    int32_t max_level;      // deepest level any group reached (what the level table must hold)
     unsigned long long visits[EGG_MAX_PASSES]; // visited pairs per collision pass, summed over tiles
     unsigned long long max_list;               // largest visit-list length any tile had in one pass
     unsigned long long rounds;                 // DAG rounds, summed over tiles and passes
@@ -107,6 +108,77 @@ static inline size_t egg_step_lds_bytes(int nmax, int amax, int ccap, int use_gr
 static inline int egg_step_threads(int nmax, int spread) {
     int t = (nmax * spread + EGG_WAVE - 1) / EGG_WAVE * EGG_WAVE;
     return t < EGG_WAVE ? EGG_WAVE : (t > 1024 ? 1024 : t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed pipeline (eggsim_packed.hip), the throughput path for many tiles per CU: one launch per phase
+// instead of one fused launch per step.  The particles of the participating tiles are kept in PACKED order
+// (tile after tile, atoms in tile order) in scratch arrays for the duration of a step; a collision pass is
+//   egg_pk_lists   (one workgroup per tile)  cell grid + visit lists in the reference's order -> global memory
+//   egg_pk_levels  (one wave per group)      longest-path level of every pair; pairs sorted by level
+//   egg_pk_exec    (one wave per group)      the group's positions in LDS; level by level, 64 pairs at a time
+// A GROUP is a run of consecutive tiles whose particles one wave keeps in LDS.  Pairs of one level share no
+// particle and all their predecessors lie in lower levels, so running the levels in order, each level's
+// pairs in any order, is the reference's sequential result bit for bit.
+struct EggPackedArgs {
+    // particle-order state of the type, atoms, claims: as in EggStepArgs
+    const double *x_in, *y_in, *vx_in, *vy_in;
+    double *x_out, *y_out, *vx_out, *vy_out;
+    const double *inv_mass, *radius;
+    const int32_t *atom_offset, *atom_count, *atom_batch;
+    const double *atom_tx, *atom_ty, *atom_fd;
+    const int32_t *atom_claim;
+    int32_t *atom_aabb_out, *atom_fail, *atom_disp_out;
+    const int32_t *tile_atom_begin;  // of this class's first tile; [n_tiles + 1]
+    const int32_t *tile_atoms;
+    int32_t n_tiles, n_groups;
+    // packed layout of this class
+    const int32_t *tile_p0;    // [n_tiles + 1] packed index of each tile's first particle
+    const int32_t *grp_tile0;  // [n_groups + 1] first tile of each group
+    int32_t p_begin, p_end;    // packed range of the class
+    // packed per-particle arrays of the type (indexed by packed index)
+    double *pk_pos, *pk_prev, *pk_vel, *pk_wr;  // double2 each
+    int32_t *pk_src;           // particle index in the particle-order arrays
+    int32_t *pk_atom;          // atom id
+    uint32_t *pk_ckey;         // [2][pk_stride] packed cell of the last pass of each sub-step parity
+    uint16_t *pk_own_cnt;      // visit-list length of each particle in the current pass
+    int32_t pk_stride;
+    // per tile (class-relative): lists[tile * lcap ..], the same for lvl and sorted
+    uint32_t *lists;           // visit entries self | slow << 15 | other << 16 (tile-local indices), reference order
+    uint16_t *lvl;             // level of each entry
+    uint32_t *sorted;          // per group from its first tile's slot: entries sorted by level, group-local indices
+    uint32_t *lev_off;         // [n_groups][lev_cap + 1] offsets of the levels inside `sorted`
+    int32_t *grp_nlev;         // [n_groups]
+    int32_t *tile_total;       // [n_tiles] entries of the current pass
+    int32_t *tile_visits;      // [EGG_PK_MAX_PASSES][n_tiles] n_collided of each pass (L:1657)
+    int32_t *tile_maxlist;     // [n_tiles] largest list of the step
+    int32_t *tile_slack;       // [n_tiles]
+    int32_t lcap, lev_cap;
+    // LDS geometry of egg_pk_lists
+    int32_t nmax, amax, ccap, use_grid;
+    // environment
+    double sub_delta, damping, follow_compliance, collision_compliance, overlap_factor, cell_size, eps;
+    int32_t n_substeps, n_collision_steps;
+    int32_t pass_seq, substep, stale;  // of the launch
+    EggStatus *status, *status_next;
+};
+#define EGG_PK_MAX_PASSES 64
+
+// dynamic LDS of egg_pk_lists for the geometry above (must match eggsim_packed.hip)
+static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int use_grid) {
+    size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, b = 0;
+    b += 2 * egg_align16(n * 16);                 // pos wr
+    b += egg_align16(2 * n * 4);                  // ckey[2]
+    b += egg_align16(2 * c * 4);                  // cell[2]
+    b += egg_align16(use_grid ? 0 : 2 * c * 4);   // hkeys[2]
+    b += egg_align16((n + 1) * 4);                // own_off
+    b += 2 * egg_align16(n * 4);                  // fill tmp
+    b += egg_align16(a * 4 * 4);                  // aclaim
+    b += egg_align16((a + 1) * 4);                // aoff
+    b += egg_align16(16 * 4);                     // scalars
+    b += egg_align16(2 * n * 2);                  // hitems[2]
+    b += 2 * egg_align16(n * 2);                  // pslot aslot
+    return b;
 }
 
 // the arguments of up to four launch classes sharing one launch (egg_step_kernel_multi*); unused slots have n_tiles = 0

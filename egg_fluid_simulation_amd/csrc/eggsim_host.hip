@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -37,6 +38,17 @@ extern "C" __global__ void egg_step_kernel_gl_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gs_mg(EggStepArgs A);
 extern "C" __global__ void egg_step_kernel_gs(EggStepArgs A);
 extern "C" __global__ void egg_selftest_arith_kernel(unsigned long long, int, unsigned long long *);
+extern "C" __global__ void egg_pk_plan_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_begin_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_mid_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_lists_fresh_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_lists_stale_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_levels8_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_levels16_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_levels64_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_exec_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_end_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_reduce_kernel(EggPackedArgs A, int n_passes);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
                                                    int, double, int32_t *);
 extern "C" __global__ void egg_rederive_kernel(const double *, double *, double *, int, int, double, double, int,
@@ -133,6 +145,24 @@ struct LaunchClass {  // tiles of similar size share a launch (uniform LDS geome
     int pair_cache = 0;    // per-pair projection terms cached in LDS (16 B per list entry)
     size_t scratch_stride = 0;
     size_t lds = 0, scratch_offset = 0;
+    int packed = -1;       // index into System::pk when the class runs through the packed pipeline (eggsim_packed.hip)
+};
+
+// A launch class in the packed pipeline: its tiles' particles occupy [p_begin, p_end) of the type's packed arrays,
+// consecutive tiles form GROUPS (one wave of egg_pk_levels / egg_pk_exec each).
+struct PackedClass {
+    int cls = 0;            // index into System::classes
+    int n_tiles = 0, n_groups = 0;
+    int p_begin = 0, p_end = 0;
+    int tile_base = 0;      // first slot of the class in the per-tile arrays
+    int group_base = 0;     // first slot in the per-group arrays
+    size_t meta_tile_p0 = 0, meta_grp_tile0 = 0;  // offsets (ints) into System::pk_meta
+    int max_group_particles = 0;
+    int wd = 8;             // lanes per tile in the level walk
+    int lcap = 0;
+    size_t entry_base = 0;  // first list entry of the class in the per-entry arrays
+    size_t lds_lists = 0, lds_levels = 0, lds_exec = 0;
+    int threads_lists = 64;
 };
 
 struct System {  // one particle type
@@ -187,6 +217,18 @@ struct System {  // one particle type
     // parameters of the step the tiles are being formed for (claims are swept along the follow motion)
     double step_follow_compliance = 57.6, step_damping = 0.9;
     int step_substeps = 2;
+    bool pk_allowed = true;  // the (sub-steps, passes) shape of the step fits the packed pipeline's per-pass tables
+    // packed pipeline (see PackedClass)
+    std::vector<PackedClass> pk;
+    std::vector<int32_t> pk_meta_host;       // tile_p0 / grp_tile0 of every packed class
+    DevBuf<int32_t> pk_meta, pk_src, pk_atom, pk_tile, pk_nlev;
+    DevBuf<double> pk_pos, pk_prev, pk_vel, pk_wr;
+    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_levoff;
+    DevBuf<uint16_t> pk_lvl, pk_own_cnt;
+    int pk_n = 0, pk_tiles = 0, pk_groups = 0;
+    size_t pk_entries = 0;                   // list entries over all packed tiles
+    int pk_lev_cap = 1023;                   // levels the tables hold; grows when a group's DAG is deeper
+    bool pk_plan_dirty = true;
     EggStatus *h_status = nullptr;  // the most recent launch's status block inside stage_down (pinned)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -218,6 +260,8 @@ struct egg_handle {
     int opt_force_single = 0;
     int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
     int opt_spin_sleep = -1;  // -1 auto
+    int opt_packed = -1;      // packed pipeline: -1 automatic (large scenes), 0 never, 1 every eligible class
+    int opt_group_particles = 1280;  // particles one wave of the packed executor keeps in LDS (16 B each)
     int opt_force_global_state = 0;  // test hook: run every tile through the global-memory-state kernel  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
     hipDeviceProp_t prop{};
     size_t lds_limit = 64 * 1024;  // dynamic LDS a step-kernel workgroup may use
@@ -753,6 +797,93 @@ int retile(egg_handle *h, int which) {
         t0 = t1;
     }
 
+    // ---- packed pipeline (eggsim_packed.hip): which classes take it, their packed ranges and groups
+    s.pk.clear();
+    s.pk_meta_host.clear();
+    s.pk_n = s.pk_tiles = s.pk_groups = 0;
+    s.pk_entries = 0;
+    {
+        // automatic: scenes large enough that the chip is full of tiles whatever the kernel (the fused kernel's
+        // latency per step is lower while every tile has a CU almost to itself); judged on the white particles so
+        // that both types of a scene take the same path
+        const bool want = h->opt_packed > 0 || (h->opt_packed < 0 && h->sys[0].n >= 200000);
+        const bool allowed = want && !single && s.gens <= 2 && s.pk_allowed;
+        for (size_t ci = 0; allowed && ci < s.classes.size(); ++ci) {
+            LaunchClass &lc = s.classes[ci];
+            if (lc.global_state || lc.nmax > 8192) continue;
+            PackedClass pc;
+            pc.cls = (int)ci;
+            pc.n_tiles = lc.n_tiles;
+            pc.lcap = lc.lcap;
+            pc.threads_lists = egg_step_threads(lc.nmax, 1);
+            pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid);
+            if (pc.lds_lists > h->lds_limit) continue;
+            pc.p_begin = s.pk_n;
+            pc.entry_base = s.pk_entries;
+            pc.tile_base = s.pk_tiles;
+            pc.group_base = s.pk_groups;
+            pc.meta_tile_p0 = s.pk_meta_host.size();
+            int pn = s.pk_n;
+            for (int t = 0; t < lc.n_tiles; ++t) {
+                s.pk_meta_host.push_back(pn);
+                pn += (int)tiles[(size_t)lc.first_tile + t].particles;
+            }
+            s.pk_meta_host.push_back(pn);
+            pc.p_end = pn;
+            // groups: consecutive tiles while one wave's LDS holds their positions (tiles are sorted by size, largest first)
+            pc.meta_grp_tile0 = s.pk_meta_host.size();
+            const int64_t gp_max = std::max<int64_t>(h->opt_group_particles, tiles[(size_t)lc.first_tile].particles);
+            int64_t in_group = 0;
+            int tiles_in_group = 0;
+            for (int t = 0; t < lc.n_tiles; ++t) {
+                const int64_t np = tiles[(size_t)lc.first_tile + t].particles;
+                if (t == 0 || in_group + np > gp_max || in_group + np > 32767 || tiles_in_group >= 64) {
+                    s.pk_meta_host.push_back(t);
+                    pc.n_groups++;
+                    in_group = 0;
+                    tiles_in_group = 0;
+                }
+                in_group += np;
+                tiles_in_group++;
+                pc.max_group_particles = std::max<int>(pc.max_group_particles, (int)in_group);
+            }
+            s.pk_meta_host.push_back(lc.n_tiles);
+            const int per_group = (lc.n_tiles + pc.n_groups - 1) / pc.n_groups;
+            pc.wd = per_group >= 8 ? 8 : per_group >= 3 ? 16 : 64;
+            pc.lds_exec = (size_t)pc.max_group_particles * 16;
+            pc.lds_levels = egg_align16((size_t)(s.pk_lev_cap + 1) * 4) + egg_align16((size_t)pc.max_group_particles * 2);
+            if (pc.lds_exec > h->lds_limit || pc.lds_levels > h->lds_limit) {
+                s.pk_meta_host.resize(pc.meta_tile_p0);
+                continue;
+            }
+            lc.packed = (int)s.pk.size();
+            s.pk_n = pn;
+            s.pk_tiles += lc.n_tiles;
+            s.pk_groups += pc.n_groups;
+            s.pk_entries += (size_t)lc.n_tiles * (size_t)lc.lcap;
+            s.pk.push_back(pc);
+        }
+        if (!s.pk.empty()) {
+            const size_t np = (size_t)s.pk_n, nt = (size_t)s.pk_tiles, ng = (size_t)s.pk_groups;
+            HIP_TRY(h, s.pk_meta.reserve(s.pk_meta_host.size() + 4, false, s.stream));
+            HIP_TRY(h, s.pk_src.reserve(np, false, s.stream));
+            HIP_TRY(h, s.pk_atom.reserve(np, false, s.stream));
+            HIP_TRY(h, s.pk_pos.reserve(2 * np, false, s.stream));
+            HIP_TRY(h, s.pk_prev.reserve(2 * np, false, s.stream));
+            HIP_TRY(h, s.pk_vel.reserve(2 * np, false, s.stream));
+            HIP_TRY(h, s.pk_wr.reserve(2 * np, false, s.stream));
+            HIP_TRY(h, s.pk_ckey.reserve(2 * np, false, s.stream));
+            HIP_TRY(h, s.pk_own_cnt.reserve(np + 8, false, s.stream));
+            HIP_TRY(h, s.pk_lists.reserve(s.pk_entries + 64, false, s.stream));
+            HIP_TRY(h, s.pk_sorted.reserve(s.pk_entries + 64, false, s.stream));
+            HIP_TRY(h, s.pk_lvl.reserve(s.pk_entries + 64, false, s.stream));
+            HIP_TRY(h, s.pk_levoff.reserve(ng * ((size_t)s.pk_lev_cap + 1) + 64, false, s.stream));
+            HIP_TRY(h, s.pk_nlev.reserve(ng + 4, false, s.stream));
+            HIP_TRY(h, s.pk_tile.reserve(nt * (3 + EGG_PK_MAX_PASSES) + 4, false, s.stream));
+        }
+        s.pk_plan_dirty = true;
+    }
+
     HIP_TRY(h, s.d_scratch.reserve(scratch_bytes + 16, false, s.stream));
     s.h_claim = claim;
     s.meta_dirty = true;
@@ -888,6 +1019,135 @@ int launch_epilogue(egg_handle *h, int which, hipStream_t stream) {
     return EGG_OK;
 }
 
+// ---- packed pipeline: one launch per phase (eggsim_packed.hip) for the classes retile() marked
+void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env &env, int S, int C, EggPackedArgs &A) {
+    System &s = h->sys[which];
+    const LaunchClass &lc = s.classes[(size_t)pc.cls];
+    memset(&A, 0, sizeof A);
+    const int in = s.cur, out = s.cur ^ 1;
+    A.x_in = s.x[in].p;
+    A.y_in = s.y[in].p;
+    A.vx_in = s.vx[in].p;
+    A.vy_in = s.vy[in].p;
+    A.x_out = s.x[out].p;
+    A.y_out = s.y[out].p;
+    A.vx_out = s.vx[out].p;
+    A.vy_out = s.vy[out].p;
+    A.inv_mass = s.inv_mass.p;
+    A.radius = s.radius.p;
+    A.atom_offset = s.d_atom_offset.p;
+    A.atom_count = s.d_atom_count.p;
+    A.atom_batch = s.d_atom_batch.p;
+    A.atom_tx = (const double *)s.d_meta.p;
+    A.atom_ty = (const double *)(s.d_meta.p + s.meta_off_ty);
+    A.atom_fd = (const double *)(s.d_meta.p + s.meta_off_fd);
+    A.atom_claim = (const int32_t *)(s.d_meta.p + s.meta_off_claim);
+    A.atom_aabb_out = d_aabb(s);
+    A.atom_fail = s.d_atom_fail.p;
+    A.atom_disp_out = d_disp(s);
+    A.tile_atom_begin = (const int32_t *)(s.d_meta.p + s.meta_off_tbegin) + lc.first_tile;
+    A.tile_atoms = (const int32_t *)(s.d_meta.p + s.meta_off_tatoms);
+    A.n_tiles = pc.n_tiles;
+    A.n_groups = pc.n_groups;
+    A.tile_p0 = s.pk_meta.p + pc.meta_tile_p0;
+    A.grp_tile0 = s.pk_meta.p + pc.meta_grp_tile0;
+    A.p_begin = pc.p_begin;
+    A.p_end = pc.p_end;
+    A.pk_pos = s.pk_pos.p;
+    A.pk_prev = s.pk_prev.p;
+    A.pk_vel = s.pk_vel.p;
+    A.pk_wr = s.pk_wr.p;
+    A.pk_src = s.pk_src.p;
+    A.pk_atom = s.pk_atom.p;
+    A.pk_ckey = s.pk_ckey.p;
+    A.pk_own_cnt = s.pk_own_cnt.p;
+    A.pk_stride = s.pk_n;
+    A.lists = s.pk_lists.p + pc.entry_base;
+    A.lvl = s.pk_lvl.p + pc.entry_base;
+    A.sorted = s.pk_sorted.p + pc.entry_base;
+    A.lev_off = s.pk_levoff.p + (size_t)pc.group_base * ((size_t)s.pk_lev_cap + 1);
+    A.grp_nlev = s.pk_nlev.p + pc.group_base;
+    int32_t *tb = s.pk_tile.p + (size_t)pc.tile_base * (3 + EGG_PK_MAX_PASSES);
+    A.tile_total = tb;
+    A.tile_maxlist = tb + pc.n_tiles;
+    A.tile_slack = tb + 2 * (size_t)pc.n_tiles;
+    A.tile_visits = tb + 3 * (size_t)pc.n_tiles;
+    A.lcap = pc.lcap;
+    A.lev_cap = s.pk_lev_cap;
+    A.nmax = lc.nmax;
+    A.amax = lc.amax;
+    A.ccap = lc.ccap;
+    A.use_grid = lc.use_grid;
+    A.sub_delta = env.sub_delta;
+    A.damping = env.damping;
+    A.follow_compliance = env.follow_c;
+    A.collision_compliance = env.collision_c;
+    A.overlap_factor = s.cfg.collision_overlap_factor;
+    A.cell_size = env.cell;
+    A.eps = s.cfg.eps;
+    A.n_substeps = S;
+    A.n_collision_steps = C;
+    A.status = d_stat(s, s.parity);
+    A.status_next = d_stat(s, s.parity ^ 1);
+}
+
+int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
+    System &s = h->sys[which];
+    const hipStream_t st = s.stream;
+    if (s.pk_plan_dirty) {
+        HIP_TRY(h, hipMemcpyAsync(s.pk_meta.p, s.pk_meta_host.data(), s.pk_meta_host.size() * sizeof(int32_t),
+                                  hipMemcpyHostToDevice, st));
+    }
+    std::vector<EggPackedArgs> args(s.pk.size());
+    for (size_t k = 0; k < s.pk.size(); ++k) fill_packed_args(h, which, s.pk[k], env, S, C, args[k]);
+    auto launch_all = [&](auto kernel_of, auto grid_of, auto block_of, auto lds_of) {
+        for (size_t k = 0; k < s.pk.size(); ++k) {
+            const PackedClass &pc = s.pk[k];
+            hipLaunchKernelGGL(kernel_of(pc), dim3((unsigned)grid_of(pc)), dim3((unsigned)block_of(pc)), lds_of(pc), st, args[k]);
+            h->stats.kernel_launches++;
+        }
+    };
+    auto flat_grid = [](const PackedClass &pc) { return (pc.p_end - pc.p_begin + 255) / 256; };
+    auto c256 = [](const PackedClass &) { return 256; };
+    auto c64 = [](const PackedClass &) { return 64; };
+    auto no_lds = [](const PackedClass &) { return (size_t)0; };
+    auto tiles_of = [](const PackedClass &pc) { return pc.n_tiles; };
+    auto groups_of = [](const PackedClass &pc) { return pc.n_groups; };
+    if (s.pk_plan_dirty) {
+        launch_all([](const PackedClass &) { return egg_pk_plan_kernel; }, tiles_of, c64, no_lds);
+        s.pk_plan_dirty = false;
+    }
+    launch_all([](const PackedClass &) { return egg_pk_begin_kernel; }, flat_grid, c256, no_lds);
+    int pass_seq = 0;
+    for (int sub = 0; sub < S; ++sub) {
+        if (sub > 0) launch_all([](const PackedClass &) { return egg_pk_mid_kernel; }, flat_grid, c256, no_lds);
+        for (int c = 0; c < C; ++c, ++pass_seq) {
+            const bool stale = c == 0 && sub > 0;  // hash lists and `collided` survive a sub-step boundary (L:1905-1912)
+            for (EggPackedArgs &A : args) {
+                A.pass_seq = pass_seq;
+                A.substep = sub;
+                A.stale = stale ? 1 : 0;
+            }
+            launch_all([&](const PackedClass &) { return stale ? egg_pk_lists_stale_kernel : egg_pk_lists_fresh_kernel; }, tiles_of,
+                       [](const PackedClass &pc) { return pc.threads_lists; }, [](const PackedClass &pc) { return pc.lds_lists; });
+            launch_all([](const PackedClass &pc) {
+                           return pc.wd == 8 ? egg_pk_levels8_kernel : pc.wd == 16 ? egg_pk_levels16_kernel : egg_pk_levels64_kernel;
+                       },
+                       groups_of, c64, [](const PackedClass &pc) { return pc.lds_levels; });
+            launch_all([](const PackedClass &) { return egg_pk_exec_kernel; }, groups_of, c64,
+                       [](const PackedClass &pc) { return pc.lds_exec; });
+        }
+    }
+    launch_all([](const PackedClass &) { return egg_pk_end_kernel; }, tiles_of, c256, no_lds);
+    const int n_passes = std::min(S * C, EGG_PK_MAX_PASSES);
+    for (size_t k = 0; k < s.pk.size(); ++k) {
+        hipLaunchKernelGGL(egg_pk_reduce_kernel, dim3(1), dim3(256), 0, st, args[k], n_passes);
+        h->stats.kernel_launches++;
+    }
+    HIP_TRY(h, hipGetLastError());
+    return EGG_OK;
+}
+
 // the throughput-tuned variant: judged by the white tiles (a yolk wave should not hold 167 registers on a full chip)
 bool use_occ_variant(const egg_handle *h, const LaunchClass &lc) {
     return std::max<int64_t>(lc.n_tiles, h->stats.n_tiles[0]) >= 4 * (int64_t)h->prop.multiProcessorCount;
@@ -901,6 +1161,7 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     s.timing_from = which;
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev0, s.stream));
     for (const LaunchClass &lc : s.classes) {
+        if (lc.packed >= 0) continue;  // stepped by the packed pipeline below
         EggStepArgs A;
         fill_args(h, which, lc, env, S, C, A);
         const dim3 grid((unsigned)lc.n_tiles), block((unsigned)lc.threads);
@@ -924,6 +1185,10 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
         HIP_TRY(h, hipGetLastError());
         h->stats.kernel_launches++;
     }
+    if (!s.pk.empty()) {
+        rc = launch_packed(h, which, env, S, C);
+        if (rc != EGG_OK) return rc;
+    }
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev1, s.stream));
     return launch_epilogue(h, which, s.stream);
 }
@@ -940,7 +1205,7 @@ bool can_fuse(const egg_handle *h) {
     int wide = -1;
     for (int w = 0; w < 2; ++w) {
         const System &s = h->sys[w];
-        if (s.n == 0 || s.classes.empty() || s.gens > 2) return false;
+        if (s.n == 0 || s.classes.empty() || s.gens > 2 || !s.pk.empty()) return false;
         for (const LaunchClass &lc : s.classes) {
             if (lc.global_lists || lc.global_state) return false;
             if (wide >= 0 && wide != lc.wide) return false;
@@ -1072,6 +1337,11 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
         s.step_follow_compliance = env[w].follow_c;
         s.step_damping = env[w].damping;
         s.step_substeps = S;
+        const bool pk_ok = S * C <= EGG_PK_MAX_PASSES;  // the packed pipeline keeps one visit counter per pass
+        if (pk_ok != s.pk_allowed) {
+            s.pk_allowed = pk_ok;
+            s.tiling_dirty = true;
+        }
     }
     if (phase == kPrepare) return prepare_tiles(h);
 
@@ -1114,6 +1384,15 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                 if (s.list_min > (size_t)kMaxGlobalListEntries)
                     return fail(h, EGG_ERR_UNSUPPORTED, "a tile visits %llu pairs in one pass; limit is %d",
                                 (unsigned long long)st.max_list, kMaxGlobalListEntries);
+                s.tiling_dirty = true;
+                redo = true;
+                continue;
+            }
+            if (st.fail_levels) {
+                // a group's pair-dependency DAG is deeper than the packed pipeline's level tables: grow and re-run
+                s.pk_lev_cap = std::max(2 * s.pk_lev_cap + 1, st.max_level + 64);
+                if (s.pk_lev_cap > 65535)
+                    return fail(h, EGG_ERR_UNSUPPORTED, "a pair-dependency chain of %d levels in one pass; limit is 65535", st.max_level);
                 s.tiling_dirty = true;
                 redo = true;
                 continue;
@@ -1334,12 +1613,19 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
             e = hipFuncSetAttribute((const void *)egg_step_kernel_mg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)egg_step_kernel_gl_mg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e == hipSuccess)
+            for (const void *f : {(const void *)egg_pk_lists_fresh_kernel, (const void *)egg_pk_lists_stale_kernel,
+                                  (const void *)egg_pk_levels8_kernel, (const void *)egg_pk_levels16_kernel,
+                                  (const void *)egg_pk_levels64_kernel, (const void *)egg_pk_exec_kernel})
+                if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess) {
             h->lds_limit = want;
             break;
         }
     }
     (void)hipGetLastError();
+    if (const char *e_pk = getenv("EGGSIM_PACKED")) h->opt_packed = atoi(e_pk);  // developer / test override of EGG_OPT_PACKED
+    if (const char *e_gp = getenv("EGGSIM_GROUP_PARTICLES")) h->opt_group_particles = std::max(1, atoi(e_gp));
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];
         s.margin = h->opt_margin;
@@ -2050,6 +2336,15 @@ int egg_set_option(egg_handle *h, int option, double value) {
             return EGG_OK;
         case EGG_OPT_SPIN_SLEEP:
             h->opt_spin_sleep = value < 0 ? -1 : (value != 0);
+            return EGG_OK;
+        case EGG_OPT_PACKED:
+            h->opt_packed = value < 0 ? -1 : (value != 0);
+            h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
+            return EGG_OK;
+        case EGG_OPT_GROUP_PARTICLES:
+            if (!(value >= 1 && value <= 10240)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "group particles must be in [1, 10240]");
+            h->opt_group_particles = (int)value;
+            h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
             return EGG_OK;
         case EGG_OPT_FORCE_SINGLE_TILE:
             h->opt_force_single = value != 0;

@@ -1,0 +1,675 @@
+// eggsim_packed.hip -- the packed pipeline: gfx950 kernels of the XPBD particle step for the throughput
+// regime (many tiles per CU).
+//
+// The fused step kernel (eggsim_step.hip) runs a tile's pair projections with a dataflow scheduler: a
+// pair runs when it is the next pending pair of both its particles.  That is exact, but a wave-instruction
+// of the projection then carries the one or two pairs of ONE island that happen to be ready (a default
+// 157-particle blob has ~6 ready pairs at any time), so a full chip issues at ~2 % lane utilisation.
+//
+// Here the same dependency order is made static.  Replacing SimulationHandler:_step's sub-step loop
+// (simulation_handler.lua:1821-1932, "L:") for the tiles of a launch class, per collision pass:
+//
+//   egg_pk_lists   one workgroup per tile.  Spatial hash (L:1486-1511) and every particle's visit list in the
+//                  reference's attempt order (L:1568-1590; the rules of eggsim_tile.h), written to global
+//                  memory in (self, position) order -- which IS the reference's sequential pair order.
+//   egg_pk_levels  one wave per GROUP of tiles.  Walks each tile's pair sequence in order and gives every
+//                  pair its level: 1 + the larger level of the previous pair of either particle (the
+//                  longest path of the pair-dependency DAG).  The walk is sequential per tile, but cheap
+//                  (integers), vectorised over the run of one `self` (a max-plus prefix scan) and over
+//                  the tiles of the group.  Then the group's pairs are counting-sorted by level.
+//   egg_pk_exec    one wave per group, the group's positions in LDS.  Level after level, 64 pairs per
+//                  wave-instruction: two pairs of one level share no particle and every predecessor of
+//                  a pair lies in a lower level, so any order inside a level gives the sequential result
+//                  bit for bit; one wave's LDS operations execute in issue order, so no barrier is needed.
+//
+// Around the passes: egg_pk_begin (gather into packed order + pre-solve + follow of the first sub-step,
+// L:1393-1471), egg_pk_mid (post-solve of a sub-step + pre-solve + follow of the next), egg_pk_end
+// (post-solve, L:1690-1693, scatter back to particle order, per-atom cell boxes / travel), egg_pk_reduce
+// (per-pass visit counts and slack: one atomic per launch instead of one per tile).
+//
+// All arithmetic is IEEE double in the reference's evaluation order: compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include "eggsim_device.h"
+
+#include "eggsim_tile.h"
+
+namespace {
+
+// ------------------------------------------------------------------ visit lists with a visitor
+// (the same rules as enum_fresh / enum_stale in eggsim_tile.h; emit(position, other) is called in attempt order)
+
+template <class F>
+__device__ inline int pk_visit_fresh(const Tile &t, int cur, int i, F emit) {
+    const uint32_t ki = t.ckey(cur)[i];
+    const uint16_t *items = t.hitems(cur);
+    int count = 0;
+    for (int p = 0; p < 3; ++p) {
+        uint32_t m[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) m[r] = cell_meta(t, cur, (uint32_t)((int)ki + (p - 1) * 65536 + (r - 1)));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int st = (int)(m[r] >> 16), cn = (int)(m[r] & 0xFFFFu);
+            for (int e = 0; e < cn; ++e) {
+                const int j = items[st + e];
+                if (j > i) {
+                    emit(count, j);
+                    ++count;
+                }
+            }
+        }
+    }
+    return count;
+}
+
+template <class F>
+__device__ inline int pk_visit_stale(const Tile &t, const PassCtx &c, int i, F emit) {
+    const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.prev);
+    const uint32_t kni = kn[i], koi = ko[i];
+    const bool settled = c.prev_uncut && kni == koi;
+    int count = 0;
+    for (int s = 0; s < 9; ++s) {
+        const uint32_t nk = (uint32_t)((int)kni + (s / 3 - 1) * 65536 + (s % 3 - 1));
+        const uint32_t mo = cell_meta(t, c.prev, nk), mn = cell_meta(t, c.cur, nk);
+#pragma unroll
+        for (int isnew = 0; isnew < 2; ++isnew) {
+            const uint32_t m = isnew ? mn : mo;
+            const uint16_t *items = t.hitems(isnew ? c.cur : c.prev);
+            const int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
+            for (int e = 0; e < cn; ++e) {
+                const int j = (int)items[st + e];
+                const uint32_t knj = kn[j], koj = ko[j];
+                if (!(settled && knj == koj) && accept_stale(t, c, i, j, s, isnew, kni, koi, knj, koj)) {
+                    emit(count, j);
+                    ++count;
+                }
+            }
+        }
+    }
+    return count;
+}
+
+// Cell records (start << 16 | count) and per-cell item lists, ascending particle index inside a cell
+// (L:1509), of generation `buf`, from the packed cells in t.ckey(buf).  tmp: n words of scratch.
+__device__ inline void pk_build_grid(const Tile &t, int buf, uint32_t *tmp, int tid, int nthreads, uint32_t *wtot) {
+    const int n = t.n;
+    for (int h = tid; h < t.ncell; h += nthreads) t.cell(buf)[h] = 0;
+    if (!t.use_grid)
+        for (int h = tid; h < t.ncell; h += nthreads) t.hkeys(buf)[h] = EGG_EMPTY_KEY;
+    for (int i = tid; i < n; i += nthreads) t.fill[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += nthreads) {
+        const uint32_t key = t.ckey(buf)[i];
+        uint32_t h;
+        if (t.use_grid) {
+            h = (key & 0xFFFFu) * (uint32_t)t.gw + (key >> 16);
+            if (h >= (uint32_t)t.ncell) h = 0;  // only after a range / claim failure
+        } else {
+            h = hash_cell(key, t.ccap);
+            for (;;) {
+                const uint32_t old = atomicCAS(&t.hkeys(buf)[h], EGG_EMPTY_KEY, key);
+                if (old == EGG_EMPTY_KEY || old == key) break;
+                h = (h + 1) & (uint32_t)(t.ccap - 1);
+            }
+        }
+        t.pslot[i] = (uint16_t)h;
+        atomicAdd(&t.cell(buf)[h], 1u);
+    }
+    __syncthreads();
+    block_exclusive_scan<true>(t.cell(buf), t.cell(buf), t.ncell, tid, nthreads, wtot);
+    __syncthreads();
+    for (int i = tid; i < n; i += nthreads) {
+        const uint32_t m = t.cell(buf)[t.pslot[i]];
+        const uint32_t pos = atomicAdd(&t.fill[m >> 16], 1u);
+        tmp[(m >> 16) + pos] = (uint32_t)i;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nthreads) {
+        const uint32_t m = t.cell(buf)[t.pslot[i]];
+        const int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
+        int rank = 0;
+        for (int e = 0; e < cn; ++e) rank += (tmp[st + e] < (uint32_t)i) ? 1 : 0;
+        t.hitems(buf)[st + rank] = (uint16_t)i;
+    }
+    __syncthreads();
+}
+
+// pre-solve (L:1393-1432) + follow constraint (L:1435-1471) of one particle, exactly as in egg_step_body
+__device__ __forceinline__ void pk_pre_follow(const EggPackedArgs &A, double2 ps, double2 &v, double im, double fx, double fy,
+                                              double target, double2 &out) {
+    v.x = v.x * A.damping;
+    v.y = v.y * A.damping;
+    double x = ps.x + A.sub_delta * v.x;
+    double y = ps.y + A.sub_delta * v.y;
+    const double dx = fx - x, dy = fy - y;
+    const double current = sqrt(dx * dx + dy * dy);
+    if (im > A.eps && current > target) {
+        double nx, ny;
+        if (current < A.eps) {
+            nx = 0.0;
+            ny = 0.0;
+        } else {
+            nx = dx / current;
+            ny = dy / current;
+        }
+        const double violation = current - target;
+        const double lambda = violation / (im + A.follow_compliance);
+        x = x + nx * lambda * im;
+        y = y + ny * lambda * im;
+    }
+    out = make_double2(x, y);
+}
+
+// inclusive prefix maximum over the WD consecutive lanes of a sub-wave (sl = lane inside it)
+template <int WD>
+__device__ __forceinline__ int subwave_incl_max(int v, int sl) {
+#pragma unroll
+    for (int s = 1; s < WD; s <<= 1) {
+        const int o = __shfl_up(v, s, WD);
+        if (sl >= s) v = max(v, o);
+    }
+    return v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Packed order: which particle / atom each packed slot holds.  One workgroup per tile, run when tiles are formed.
+extern "C" __global__ void __launch_bounds__(64) egg_pk_plan_kernel(EggPackedArgs A) {
+    const int tile = blockIdx.x;
+    if (tile >= A.n_tiles) return;
+    const int a0 = A.tile_atom_begin[tile], a1 = A.tile_atom_begin[tile + 1];
+    int p = A.tile_p0[tile];
+    for (int k = a0; k < a1; ++k) {
+        const int atom = A.tile_atoms[k];
+        const int g0 = A.atom_offset[atom], cnt = A.atom_count[atom];
+        for (int q = threadIdx.x; q < cnt; q += 64) {
+            A.pk_src[p + q] = g0 + q;
+            A.pk_atom[p + q] = atom;
+        }
+        p += cnt;
+    }
+}
+
+// Start of a step: gather into packed order, pre-solve + follow of the first sub-step.
+extern "C" __global__ void __launch_bounds__(256) egg_pk_begin_kernel(EggPackedArgs A) {
+    if (blockIdx.x == 0 && A.status_next) {
+        // nothing touches the other status block while this step runs: give it its initial state
+        unsigned long long *q = (unsigned long long *)A.status_next;
+        for (int w = threadIdx.x; w < (int)(sizeof(EggStatus) / 8); w += 256) q[w] = 0ull;
+        __syncthreads();
+        if (threadIdx.x == 0) A.status_next->min_slack = 0x7FFFFFFF;
+    }
+    const int p = A.p_begin + (int)(blockIdx.x * 256 + threadIdx.x);
+    if (p >= A.p_end) return;
+    const int g = A.pk_src[p], atom = A.pk_atom[p];
+    const double2 ps = make_double2(A.x_in[g], A.y_in[g]);
+    double2 v = make_double2(A.vx_in[g], A.vy_in[g]);
+    const double2 wr = make_double2(A.inv_mass[g], A.radius[g]);
+    double2 out;
+    pk_pre_follow(A, ps, v, wr.x, A.atom_tx[atom], A.atom_ty[atom], A.atom_fd[atom], out);
+    ((double2 *)A.pk_prev)[p] = ps;
+    ((double2 *)A.pk_vel)[p] = v;
+    ((double2 *)A.pk_pos)[p] = out;
+    ((double2 *)A.pk_wr)[p] = wr;
+}
+
+// Between two sub-steps: post-solve of the one (L:1690-1693), pre-solve + follow of the next.
+extern "C" __global__ void __launch_bounds__(256) egg_pk_mid_kernel(EggPackedArgs A) {
+    const int p = A.p_begin + (int)(blockIdx.x * 256 + threadIdx.x);
+    if (p >= A.p_end) return;
+    const int atom = A.pk_atom[p];
+    const double2 ps = ((const double2 *)A.pk_pos)[p], pv = ((const double2 *)A.pk_prev)[p];
+    double2 v = make_double2((ps.x - pv.x) / A.sub_delta, (ps.y - pv.y) / A.sub_delta);
+    const double im = ((const double2 *)A.pk_wr)[p].x;
+    double2 out;
+    pk_pre_follow(A, ps, v, im, A.atom_tx[atom], A.atom_ty[atom], A.atom_fd[atom], out);
+    ((double2 *)A.pk_prev)[p] = ps;
+    ((double2 *)A.pk_vel)[p] = v;
+    ((double2 *)A.pk_pos)[p] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One collision pass, phase 1: spatial hash + visit lists of a tile.
+template <bool STALE>
+__device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int tile = blockIdx.x;
+    if (tile >= A.n_tiles) return;
+    Tile t;
+    uint32_t *own_off, *tmp;
+    {
+        const size_t n = (size_t)A.nmax, a = (size_t)A.amax, cc = (size_t)A.ccap;
+        unsigned char *p = smem;
+        t.pos = (double2 *)carve(p, n * 16);
+        t.wr = (double2 *)carve(p, n * 16);
+        t.ckey_b = (uint32_t *)carve(p, 2 * n * 4);
+        t.cell_b = (uint32_t *)carve(p, 2 * cc * 4);
+        t.hkeys_b = (uint32_t *)carve(p, A.use_grid ? 0 : 2 * cc * 4);
+        own_off = (uint32_t *)carve(p, (n + 1) * 4);
+        t.fill = (uint32_t *)carve(p, n * 4);
+        tmp = (uint32_t *)carve(p, n * 4);
+        t.aclaim = (int32_t *)carve(p, a * 4 * 4);
+        t.aoff = (int32_t *)carve(p, (a + 1) * 4);
+        t.sc = (int32_t *)carve(p, 16 * 4);
+        t.hitems_b = (uint16_t *)carve(p, 2 * n * 2);
+        t.pslot = (uint16_t *)carve(p, n * 2);
+        t.aslot = (uint16_t *)carve(p, n * 2);
+        t.s_n = (int)n;
+        t.s_c = (int)cc;
+        t.s_o = 0;
+        t.s_l = 0;
+        t.ccap = A.ccap;
+        t.lcap = A.lcap;
+        t.use_grid = A.use_grid;
+        t.own_off_b = own_off;
+        t.own_ent_b = nullptr;  // never read: the previous pass is never cut here (prev_uncut)
+        t.inc_tmp = tmp;
+    }
+    __shared__ uint32_t wtot[16];
+
+    const int a_begin = A.tile_atom_begin[tile];
+    const int na = A.tile_atom_begin[tile + 1] - a_begin;
+    t.na = na;
+    const int p0 = A.tile_p0[tile];
+    if (tid == 0) {
+        int off = 0;
+        int ox = 0x7FFFFFFF, oy = 0x7FFFFFFF, hx = -0x7FFFFFFF, hy = -0x7FFFFFFF;
+        for (int k = 0; k < na; ++k) {
+            const int atom = A.tile_atoms[a_begin + k];
+            if (A.pass_seq == 0) A.atom_fail[atom] = 0;
+            t.aoff[k] = off;
+            off += A.atom_count[atom];
+            for (int q = 0; q < 4; ++q) t.aclaim[4 * k + q] = A.atom_claim[4 * atom + q];
+            ox = min(ox, t.aclaim[4 * k + 0]);
+            oy = min(oy, t.aclaim[4 * k + 1]);
+            hx = max(hx, t.aclaim[4 * k + 2]);
+            hy = max(hy, t.aclaim[4 * k + 3]);
+        }
+        t.aoff[na] = off;
+        t.sc[2] = off;
+        t.sc[3] = ox - 2;  // packed cells are relative to (ox - 2, oy - 2), see egg_step_body
+        t.sc[4] = oy - 2;
+        const long long gw = (long long)hx - ox + 4, gh = (long long)hy - oy + 4;
+        t.sc[6] = (int)min(gw, 65535ll);
+        t.sc[7] = (int)min(gh, 65535ll);
+        if (gw > 65534ll || gh > 65534ll) atomicExch(&A.status->fail_range, 1);
+        if (A.use_grid && gw * gh > (long long)A.ccap) atomicExch(&A.status->fail_overflow, 1);
+        if (off > A.nmax || na > A.amax) atomicExch(&A.status->fail_overflow, 1);
+    }
+    __syncthreads();
+    const int n = __builtin_amdgcn_readfirstlane(min(t.sc[2], A.nmax));
+    t.n = n;
+    const int org_x = __builtin_amdgcn_readfirstlane(t.sc[3]), org_y = __builtin_amdgcn_readfirstlane(t.sc[4]);
+    t.gw = __builtin_amdgcn_readfirstlane(t.sc[6]);
+    t.ncell = A.use_grid ? __builtin_amdgcn_readfirstlane((int)min((long long)t.sc[6] * t.sc[7], (long long)A.ccap)) : A.ccap;
+
+    for (int k = 0; k < na; ++k) {
+        const int l0 = t.aoff[k], cnt = t.aoff[k + 1] - l0;
+        for (int q = tid; q < cnt; q += nthreads)
+            if (l0 + q < n) t.aslot[l0 + q] = (uint16_t)k;
+    }
+    const int cur = 0, prev = 1;  // LDS generation buffers of this launch
+    uint32_t *g_ckey_cur = A.pk_ckey + (size_t)(A.substep & 1) * A.pk_stride + p0;
+    const uint32_t *g_ckey_prev = A.pk_ckey + (size_t)((A.substep + 1) & 1) * A.pk_stride + p0;
+    for (int i = tid; i < n; i += nthreads) {
+        t.pos[i] = ((const double2 *)A.pk_pos)[p0 + i];
+        t.wr[i] = ((const double2 *)A.pk_wr)[p0 + i];
+        if (STALE) t.ckey(prev)[i] = g_ckey_prev[i];
+    }
+    __syncthreads();
+
+    // ----------------------------------- spatial hash of this pass, L:1486-1511 (claim check as in egg_step_body)
+    bool bad = false;
+    for (int i = tid; i < n; i += nthreads) {
+        const double2 ps = t.pos[i];
+        const double fcx = floor(ps.x / A.cell_size);
+        const double fcy = floor(ps.y / A.cell_size);
+        const int32_t *cl = &t.aclaim[4 * t.aslot[i]];
+        int cx = (fcx >= -2.0e9 && fcx <= 2.0e9) ? (int)fcx : 0x7FFFFFF0;
+        int cy = (fcy >= -2.0e9 && fcy <= 2.0e9) ? (int)fcy : 0x7FFFFFF0;
+        if (cx < cl[0] || cx > cl[2] || cy < cl[1] || cy > cl[3]) {
+            bad = true;
+            A.atom_fail[A.tile_atoms[a_begin + t.aslot[i]]] = 1;
+            cx = cl[0];
+            cy = cl[1];
+        }
+        const uint32_t key = ((uint32_t)(cx - org_x) << 16) | (uint32_t)(cy - org_y);
+        t.ckey(cur)[i] = key;
+        g_ckey_cur[i] = key;
+    }
+    const bool any_bad = __syncthreads_or(bad) != 0;
+    int total = 0;
+    uint32_t guarded = 0;
+    if (!any_bad) {
+        pk_build_grid(t, cur, tmp, tid, nthreads, wtot);
+        if (STALE) pk_build_grid(t, prev, tmp, tid, nthreads, wtot);
+        PassCtx ctx;
+        ctx.cur = cur;
+        ctx.prev = prev;
+        ctx.live = STALE ? 1 : 0;
+        ctx.G = 2;
+        ctx.stale = STALE ? 1 : 0;
+        ctx.prev_uncut = 1;  // the budget never cuts a multi-tile pass (the host checks the visit counts afterwards)
+        ctx.cut_mask = 0;
+
+        // ---------------------------------------- visit lists: count, offsets, fill
+        for (int i = tid; i < n; i += nthreads)
+            t.fill[i] = STALE ? (uint32_t)enum_stale<0>(t, ctx, i, nullptr) : (uint32_t)enum_fresh<false>(t, cur, i, nullptr);
+        __syncthreads();
+        block_exclusive_scan<false>(t.fill, own_off, n, tid, nthreads, wtot);
+        __syncthreads();
+        total = (int)own_off[n];
+    }
+    const bool fits = total <= A.lcap;
+    if (tid == 0) {
+        if (any_bad) atomicExch(&A.status->fail_claim, 1);
+        if (!fits) atomicExch(&A.status->fail_overflow, 1);
+        const int before = A.pass_seq == 0 ? 0 : A.tile_maxlist[tile];
+        A.tile_maxlist[tile] = max(before, total);  // what the pass needs, even when it does not fit
+        A.tile_total[tile] = fits ? total : 0;
+    }
+    // a tile that failed a check gets empty lists: the later phases then leave it alone (the step is re-run)
+    const bool emit_lists = !any_bad && fits;
+    uint32_t *glist = A.lists + (size_t)tile * A.lcap;
+    for (int i = tid; i < n; i += nthreads) {
+        int cnt = 0;
+        if (emit_lists) {
+            const double2 wi = t.wr[i];
+            uint32_t *dst = glist + own_off[i];
+            auto emit = [&](int k, int j) {
+                const double2 wj = t.wr[j];
+                const bool slow = pair_needs_reference(wi, wj, A.overlap_factor, A.collision_compliance, A.eps);
+                // a pair failing the mass guard (L:1601) is marked in `collided` but leaves n_collided alone
+                if (slow && wi.x + wj.x < A.eps) ++guarded;
+                dst[k] = (uint32_t)i | (slow ? 0x8000u : 0u) | ((uint32_t)j << 16);
+            };
+            PassCtx ctx;
+            ctx.cur = cur;
+            ctx.prev = prev;
+            ctx.live = STALE ? 1 : 0;
+            ctx.G = 2;
+            ctx.stale = STALE ? 1 : 0;
+            ctx.prev_uncut = 1;
+            ctx.cut_mask = 0;
+            cnt = STALE ? pk_visit_stale(t, ctx, i, emit) : pk_visit_fresh(t, cur, i, emit);
+        }
+        A.pk_own_cnt[p0 + i] = (uint16_t)cnt;
+    }
+    // n_collided of this tile and pass: visited pairs that passed the mass guard
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) guarded += __shfl_xor(guarded, d, 64);
+    if ((tid & 63) == 0) wtot[tid >> 6] = guarded;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t gsum = 0;
+        for (int w = 0; w < (nthreads + 63) / 64; ++w) gsum += wtot[w];
+        A.tile_visits[(size_t)min(A.pass_seq, EGG_PK_MAX_PASSES - 1) * A.n_tiles + tile] = emit_lists ? total - (int)gsum : 0;
+    }
+}
+extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_fresh_kernel(EggPackedArgs A) { egg_pk_lists_body<false>(A); }
+extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_stale_kernel(EggPackedArgs A) { egg_pk_lists_body<true>(A); }
+
+// ------------------------------------------------------------------------------------------------
+// Phase 2: levels.  One wave per group; a sub-wave of WD lanes walks one tile's pair sequence.
+//
+// Sequential definition: for the pairs e = (a, b) in the reference's order, level(e) = 1 + max(last[a], last[b]),
+// then last[a] = last[b] = level(e).  The run of one self a (partners b_0 .. b_m-1, all different, none equal
+// to a) gives  l_k = max(l_{k-1}, last[b_k]) + 1  with l_{-1} = last[a], i.e.
+// l_k = k + 1 + max(last[a], max_{j <= k}(last[b_j] - j)): a prefix maximum over the lanes of the sub-wave.
+template <int WD>
+__device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int g = blockIdx.x;
+    if (g >= A.n_groups) return;
+    const int lane = threadIdx.x;
+    const int t0 = A.grp_tile0[g], t1 = A.grp_tile0[g + 1];
+    const int p0 = A.tile_p0[t0], np = A.tile_p0[t1] - p0;
+    const int lev_cap = A.lev_cap;
+    uint32_t *hist = (uint32_t *)smem;                       // [lev_cap + 1] pairs per level, then the running fill offsets
+    uint16_t *last = (uint16_t *)(smem + egg_align16((size_t)(lev_cap + 1) * 4));  // [np] level of the last pair of each particle
+    for (int i = lane; i <= lev_cap; i += 64) hist[i] = 0;
+    for (int i = lane; i < np; i += 64) last[i] = 0;
+    // (one wave: its LDS operations execute in issue order, no barrier needed)
+    const int sub = lane / WD, sl = lane % WD;
+    constexpr int NSUB = 64 / WD;
+    int maxlev = 0;
+    bool over = false;
+    for (int ti = t0 + sub; ti < t1; ti += NSUB) {
+        const int tp0 = A.tile_p0[ti], n = A.tile_p0[ti + 1] - tp0, base = tp0 - p0;
+        const uint32_t *list = A.lists + (size_t)ti * A.lcap;
+        uint16_t *lv = A.lvl + (size_t)ti * A.lcap;
+        const int total = A.tile_total[ti];
+        int off = 0;
+        for (int a = 0; a < n && off < total; ++a) {
+            const int cnt = (int)A.pk_own_cnt[tp0 + a];
+            if (cnt == 0) continue;
+            int x0 = (int)last[base + a];
+            for (int k0 = 0; k0 < cnt; k0 += WD) {
+                const int k = k0 + sl;
+                const bool valid = k < cnt;
+                const uint32_t rec = valid ? list[off + k] : 0u;
+                const int b = (int)((rec >> 16) & 0x7FFFu);
+                const int c = valid ? (int)last[base + b] : 0;
+                const int d = valid ? c - sl : -0x40000000;
+                const int pm = subwave_incl_max<WD>(d, sl);
+                int l = sl + 1 + max(x0, pm);
+                if (l > lev_cap) {  // deeper than the level table: report what is needed, keep the tables in range
+                    over = true;
+                    maxlev = max(maxlev, l);
+                    l = lev_cap;
+                }
+                if (valid) {
+                    last[base + b] = (uint16_t)l;
+                    lv[off + k] = (uint16_t)l;
+                    atomicAdd(&hist[l], 1u);
+                }
+                x0 = __shfl(l, min(cnt - k0, WD) - 1, WD);
+            }
+            if (sl == 0) last[base + a] = (uint16_t)x0;
+            maxlev = max(maxlev, x0);
+            off += cnt;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxlev = max(maxlev, __shfl_xor(maxlev, d, 64));
+    over = __any(over);
+    if (over && lane == 0) {
+        atomicExch(&A.status->fail_levels, 1);
+        atomicMax(&A.status->max_level, maxlev);
+    }
+    const int nlev = min(maxlev, lev_cap);
+    // offsets of the levels inside the group's sorted list: exclusive scan of the histogram (level 0 is empty)
+    uint32_t *goff = A.lev_off + (size_t)g * (lev_cap + 1);
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 <= nlev; b0 += 64) {
+        const int L = b0 + lane;
+        const uint32_t v = (L <= nlev) ? hist[L] : 0u;
+        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane);
+        const uint32_t excl = carry + incl - v;
+        if (L <= nlev) {
+            // goff[L] = end of level L (= start of level L + 1); level L's pairs are [goff[L - 1], goff[L])
+            goff[L] = excl + v;
+            hist[L] = excl;
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) A.grp_nlev[g] = over ? 0 : nlev;  // an overflowed group is left alone by the executor (the step is re-run)
+    // counting sort: every pair to its level's slot range, indices made group-local
+    uint32_t *sorted = A.sorted + (size_t)t0 * A.lcap;
+    for (int ti = t0; ti < t1; ++ti) {
+        const uint32_t base = (uint32_t)(A.tile_p0[ti] - p0);
+        const uint32_t *list = A.lists + (size_t)ti * A.lcap;
+        const uint16_t *lv = A.lvl + (size_t)ti * A.lcap;
+        const int total = A.tile_total[ti];
+        for (int e = lane; e < total; e += 64) {
+            const uint32_t rec = list[e];
+            const uint32_t l = lv[e];
+            const uint32_t pos = atomicAdd(&hist[l], 1u);
+            sorted[pos] = ((rec & 0x7FFFu) + base) | (rec & 0x8000u) | ((((rec >> 16) & 0x7FFFu) + base) << 16);
+        }
+    }
+}
+extern "C" __global__ void __launch_bounds__(64) egg_pk_levels8_kernel(EggPackedArgs A) { egg_pk_levels_body<8>(A); }
+extern "C" __global__ void __launch_bounds__(64) egg_pk_levels16_kernel(EggPackedArgs A) { egg_pk_levels_body<16>(A); }
+extern "C" __global__ void __launch_bounds__(64) egg_pk_levels64_kernel(EggPackedArgs A) { egg_pk_levels_body<64>(A); }
+
+// ------------------------------------------------------------------------------------------------
+// Phase 3: the pair projections (L:1514-1545, L:1632-1654), level by level, 64 pairs per wave-instruction.
+extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *lpos = (double2 *)smem;
+    const int g = blockIdx.x;
+    if (g >= A.n_groups) return;
+    const int lane = threadIdx.x;
+    const int t0 = A.grp_tile0[g], t1 = A.grp_tile0[g + 1];
+    const int p0 = A.tile_p0[t0], np = A.tile_p0[t1] - p0;
+    const int nlev = A.grp_nlev[g];
+    if (nlev <= 0) return;  // nothing to do: positions stay as they are
+    double2 *gpos = (double2 *)A.pk_pos + p0;
+    const double2 *gwr = (const double2 *)A.pk_wr + p0;
+    for (int i = lane; i < np; i += 64) lpos[i] = gpos[i];
+    const uint32_t *sorted = A.sorted + (size_t)t0 * A.lcap;
+    const uint32_t *goff = A.lev_off + (size_t)g * (A.lev_cap + 1);
+    const double overlap = A.overlap_factor, compliance = A.collision_compliance, eps = A.eps;
+    uint32_t start = 0;
+    for (int L = 1; L <= nlev; ++L) {
+        const uint32_t end = goff[L];
+        for (uint32_t e0 = start; e0 < end; e0 += 64) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            if (e < end) {
+                const uint32_t rec = sorted[e];
+                const int ga = (int)(rec & 0x7FFFu), gb = (int)((rec >> 16) & 0x7FFFu);
+                double2 pa = lpos[ga], pb = lpos[gb];
+                const double2 wra = gwr[ga], wrb = gwr[gb];
+                project_pair<false>(
+                    [&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
+                    (rec & 0x8000u) != 0, pa, pb, wra, wrb, wra, overlap, compliance, eps);
+                lpos[ga] = pa;
+                lpos[gb] = pb;
+            }
+        }
+        start = end;
+    }
+    for (int i = lane; i < np; i += 64) gpos[i] = lpos[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// End of a step: post-solve of the last sub-step (L:1690-1693), scatter to particle order, per-atom cell boxes
+// and last-sub-step travel (what the host sizes the next step's claims with), slack to the claim edges.
+extern "C" __global__ void __launch_bounds__(256) egg_pk_end_kernel(EggPackedArgs A) {
+    const int tile = blockIdx.x;
+    if (tile >= A.n_tiles) return;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int a_begin = A.tile_atom_begin[tile], na = A.tile_atom_begin[tile + 1] - a_begin;
+    __shared__ int32_t red[8];
+    __shared__ int32_t wslack[4];
+    int slack = 0x7FFFFFFF;
+    int p = A.tile_p0[tile];
+    for (int k = 0; k < na; ++k) {
+        const int atom = A.tile_atoms[a_begin + k];
+        const int cnt = A.atom_count[atom];
+        __syncthreads();
+        if (tid < 8) red[tid] = (tid < 2) ? 0x7FFFFFFF : (tid < 4) ? -0x7FFFFFFF : 0;
+        __syncthreads();
+        int32_t cl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cl[q] = A.atom_claim[4 * atom + q];
+        int lo_x = 0x7FFFFFFF, lo_y = 0x7FFFFFFF, hi_x = -0x7FFFFFFF, hi_y = -0x7FFFFFFF;
+        int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        for (int q = tid; q < cnt; q += nthreads) {
+            const int g = A.pk_src[p + q];
+            const double2 ps = ((const double2 *)A.pk_pos)[p + q], pv = ((const double2 *)A.pk_prev)[p + q];
+            const double2 v = make_double2((ps.x - pv.x) / A.sub_delta, (ps.y - pv.y) / A.sub_delta);
+            A.x_out[g] = ps.x;
+            A.y_out[g] = ps.y;
+            A.vx_out[g] = v.x;
+            A.vy_out[g] = v.y;
+            const double fcx = floor(ps.x / A.cell_size), fcy = floor(ps.y / A.cell_size);
+            const int cx = (fcx >= -2.0e9 && fcx <= 2.0e9) ? (int)fcx : 0x7FFFFFF0;
+            const int cy = (fcy >= -2.0e9 && fcy <= 2.0e9) ? (int)fcy : 0x7FFFFFF0;
+            lo_x = min(lo_x, cx);
+            lo_y = min(lo_y, cy);
+            hi_x = max(hi_x, cx);
+            hi_y = max(hi_y, cy);
+            const double ddx = ps.x - pv.x, ddy = ps.y - pv.y;
+            const int qx = (int)fmin(fmax(ddx * 16.0, -2.0e9), 2.0e9), qy = (int)fmin(fmax(ddy * 16.0, -2.0e9), 2.0e9);
+            if (qx >= 0) d0 = max(d0, qx); else d1 = max(d1, -qx);
+            if (qy >= 0) d2 = max(d2, qy); else d3 = max(d3, -qy);
+            slack = min(slack, min(min(cx - cl[0], cl[2] - cx), min(cy - cl[1], cl[3] - cy)));
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, d, 64));
+            lo_y = min(lo_y, __shfl_xor(lo_y, d, 64));
+            hi_x = max(hi_x, __shfl_xor(hi_x, d, 64));
+            hi_y = max(hi_y, __shfl_xor(hi_y, d, 64));
+            d0 = max(d0, __shfl_xor(d0, d, 64));
+            d1 = max(d1, __shfl_xor(d1, d, 64));
+            d2 = max(d2, __shfl_xor(d2, d, 64));
+            d3 = max(d3, __shfl_xor(d3, d, 64));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&red[0], lo_x);
+            atomicMin(&red[1], lo_y);
+            atomicMax(&red[2], hi_x);
+            atomicMax(&red[3], hi_y);
+            atomicMax(&red[4], d0);
+            atomicMax(&red[5], d1);
+            atomicMax(&red[6], d2);
+            atomicMax(&red[7], d3);
+        }
+        __syncthreads();
+        if (tid < 4) A.atom_aabb_out[4 * atom + tid] = red[tid];
+        else if (tid < 8) A.atom_disp_out[4 * atom + tid - 4] = red[tid];
+        p += cnt;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) slack = min(slack, __shfl_xor(slack, d, 64));
+    if ((tid & 63) == 0) wslack[tid >> 6] = slack;
+    __syncthreads();
+    if (tid == 0) {
+        int s = wslack[0];
+        for (int w = 1; w < (nthreads + 63) / 64; ++w) s = min(s, wslack[w]);
+        A.tile_slack[tile] = s;
+    }
+}
+
+// One workgroup: the per-tile counters of the class become the step's status entries (one atomic each instead of
+// one per tile: thousands of same-address atomics would serialise at ~12 ns apiece).
+extern "C" __global__ void __launch_bounds__(256) egg_pk_reduce_kernel(EggPackedArgs A, int n_passes) {
+    __shared__ long long wsum[4];
+    __shared__ int wmin[4], wmax[4];
+    const int tid = threadIdx.x;
+    for (int ps = 0; ps < n_passes; ++ps) {
+        long long s = 0;
+        const int32_t *v = A.tile_visits + (size_t)ps * A.n_tiles;
+        for (int t = tid; t < A.n_tiles; t += 256) s += v[t];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) wsum[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) atomicAdd(&A.status->visits[ps], (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+    }
+    int slack = 0x7FFFFFFF, ml = 0;
+    for (int t = tid; t < A.n_tiles; t += 256) {
+        slack = min(slack, A.tile_slack[t]);
+        ml = max(ml, A.tile_maxlist[t]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        slack = min(slack, __shfl_xor(slack, d, 64));
+        ml = max(ml, __shfl_xor(ml, d, 64));
+    }
+    if ((tid & 63) == 0) {
+        wmin[tid >> 6] = slack;
+        wmax[tid >> 6] = ml;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomicMin(&A.status->min_slack, min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3])));
+        atomicMax(&A.status->max_list, (unsigned long long)max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+    }
+}

@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="coincident batches per site (4 = BASELINE config 3; not the headline config)")
     ap.add_argument("--no-fuse", action="store_true", help="one launch per particle type even on a full chip (A/B testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--packed", type=int, default=-1, help="packed pipeline: -1 automatic, 0 never, 1 always (A/B testing)")
+    ap.add_argument("--group-particles", type=int, default=0, help="packed pipeline: particles per executor wave (0 = default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,6 +124,10 @@ def main():
         h.set_option(_ffi.OPT_TILE_TARGET_PARTICLES, args.tile_target)
     if args.no_fuse:
         h.set_option(_ffi.OPT_FUSE_TYPES, 0)
+    if args.packed >= 0:
+        h.set_option(_ffi.OPT_PACKED, args.packed)
+    if args.group_particles:
+        h.set_option(_ffi.OPT_GROUP_PARTICLES, args.group_particles)
     xs, ys, side = grid_positions(args.batches, column_offset=rank, overlap=args.overlap)
     ids = h.add_many(xs, ys, 50, 15)
     n_white, n_yolk = h.get_n_particles()

@@ -137,25 +137,26 @@ struct EggPackedArgs {
     const int32_t *grp_tile0;  // [n_groups + 1] first tile of each group
     int32_t p_begin, p_end;    // packed range of the class
     // packed per-particle arrays of the type (indexed by packed index)
-    double *pk_pos, *pk_prev, *pk_vel, *pk_wr;  // double2 each
+    double *pk_pos, *pk_prev, *pk_wr;  // double2 each: position, position at the start of the sub-step, (inverse mass, radius)
     int32_t *pk_src;           // particle index in the particle-order arrays
     int32_t *pk_atom;          // atom id
     uint32_t *pk_ckey;         // [2][pk_stride] packed cell of the last pass of each sub-step parity
-    uint16_t *pk_own_cnt;      // visit-list length of each particle in the current pass
     int32_t pk_stride;
-    // per tile (class-relative): lists[tile * lcap ..], the same for lvl and sorted
-    uint32_t *lists;           // visit entries self | slow << 15 | other << 16 (tile-local indices), reference order
-    uint16_t *lvl;             // level of each entry
-    uint32_t *sorted;          // per group from its first tile's slot: entries sorted by level, group-local indices
-    uint32_t *lev_off;         // [n_groups][lev_cap + 1] offsets of the levels inside `sorted`
-    int32_t *grp_nlev;         // [n_groups]
-    int32_t *tile_total;       // [n_tiles] entries of the current pass
+    // per tile (class-relative), `scap` words each: the tile's pair STREAM in the reference's order -- the visit
+    // entries self | slow << 15 | other << 16 (tile-local indices) of every particle as `self`, ascending
+    uint32_t *lists;
+    uint16_t *lvl;             // level of each stream entry
+    uint32_t *sorted;          // per group, from its first tile's slot: entries sorted by level, group-local indices
+    uint32_t *chunks;          // [n_groups][chunk_cap] the executor's work list: start | (count - 1) << 26 into `sorted`,
+                               // every chunk inside one level, levels ascending
+    int32_t *grp_nchunks;      // [n_groups]
+    int32_t *tile_total;       // [n_tiles] visit entries of the current pass
     int32_t *tile_visits;      // [EGG_PK_MAX_PASSES][n_tiles] n_collided of each pass (L:1657)
     int32_t *tile_maxlist;     // [n_tiles] largest list of the step
     int32_t *tile_slack;       // [n_tiles]
-    int32_t lcap, lev_cap;
+    int32_t lcap, scap, lev_cap, chunk_cap;
     // LDS geometry of egg_pk_lists
-    int32_t nmax, amax, ccap, use_grid;
+    int32_t nmax, amax, ccap, use_grid, stage_cap;
     // environment
     double sub_delta, damping, follow_compliance, collision_compliance, overlap_factor, cell_size, eps;
     int32_t n_substeps, n_collision_steps;
@@ -163,9 +164,10 @@ struct EggPackedArgs {
     EggStatus *status, *status_next;
 };
 #define EGG_PK_MAX_PASSES 64
+#define EGG_PK_WINDOW 128  // stream words a sub-wave of egg_pk_levels holds in LDS at a time
 
 // dynamic LDS of egg_pk_lists for the geometry above (must match eggsim_packed.hip)
-static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int use_grid) {
+static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int use_grid, int stage_cap) {
     size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, b = 0;
     b += 2 * egg_align16(n * 16);                 // pos wr
     b += egg_align16(2 * n * 4);                  // ckey[2]
@@ -178,7 +180,13 @@ static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int us
     b += egg_align16(16 * 4);                     // scalars
     b += egg_align16(2 * n * 2);                  // hitems[2]
     b += 2 * egg_align16(n * 2);                  // pslot aslot
+    b += egg_align16((size_t)stage_cap * n * 2);  // partners kept by the counting pass
     return b;
+}
+// dynamic LDS of egg_pk_levels: level histogram, last level per particle of the group, one stream window per sub-wave
+static inline size_t egg_pk_levels_lds_bytes(int lev_cap, int group_particles, int wd) {
+    return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 2) +
+           egg_align16((size_t)(64 / wd) * EGG_PK_WINDOW * 4);
 }
 
 // the arguments of up to four launch classes sharing one launch (egg_step_kernel_multi*); unused slots have n_tiles = 0

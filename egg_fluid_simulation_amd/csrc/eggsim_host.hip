@@ -159,8 +159,11 @@ struct PackedClass {
     size_t meta_tile_p0 = 0, meta_grp_tile0 = 0;  // offsets (ints) into System::pk_meta
     int max_group_particles = 0;
     int wd = 8;             // lanes per tile in the level walk
-    int lcap = 0;
-    size_t entry_base = 0;  // first list entry of the class in the per-entry arrays
+    int lcap = 0, scap = 0;  // visit entries / stream words (entries + one header per particle) a tile may have
+    int stage_cap = 0;       // partners per particle the list kernel's counting pass keeps in LDS
+    int chunk_cap = 0;       // chunk descriptors per group
+    size_t chunk_base = 0;
+    size_t entry_base = 0;  // first stream word of the class in the per-entry arrays
     size_t lds_lists = 0, lds_levels = 0, lds_exec = 0;
     int threads_lists = 64;
 };
@@ -221,12 +224,13 @@ struct System {  // one particle type
     // packed pipeline (see PackedClass)
     std::vector<PackedClass> pk;
     std::vector<int32_t> pk_meta_host;       // tile_p0 / grp_tile0 of every packed class
-    DevBuf<int32_t> pk_meta, pk_src, pk_atom, pk_tile, pk_nlev;
-    DevBuf<double> pk_pos, pk_prev, pk_vel, pk_wr;
-    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_levoff;
-    DevBuf<uint16_t> pk_lvl, pk_own_cnt;
+    DevBuf<int32_t> pk_meta, pk_src, pk_atom, pk_tile, pk_nchunks;
+    DevBuf<double> pk_pos, pk_prev, pk_wr;
+    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_chunks;
+    DevBuf<uint16_t> pk_lvl;
     int pk_n = 0, pk_tiles = 0, pk_groups = 0;
-    size_t pk_entries = 0;                   // list entries over all packed tiles
+    size_t pk_entries = 0;                   // stream words over all packed tiles
+    size_t pk_chunk_words = 0;               // chunk descriptors over all packed groups
     int pk_lev_cap = 1023;                   // levels the tables hold; grows when a group's DAG is deeper
     bool pk_plan_dirty = true;
     EggStatus *h_status = nullptr;  // the most recent launch's status block inside stage_down (pinned)
@@ -802,6 +806,7 @@ int retile(egg_handle *h, int which) {
     s.pk_meta_host.clear();
     s.pk_n = s.pk_tiles = s.pk_groups = 0;
     s.pk_entries = 0;
+    s.pk_chunk_words = 0;
     {
         // automatic: scenes large enough that the chip is full of tiles whatever the kernel (the fused kernel's
         // latency per step is lower while every tile has a CU almost to itself); judged on the white particles so
@@ -815,8 +820,14 @@ int retile(egg_handle *h, int which) {
             pc.cls = (int)ci;
             pc.n_tiles = lc.n_tiles;
             pc.lcap = lc.lcap;
+            pc.scap = lc.lcap;
             pc.threads_lists = egg_step_threads(lc.nmax, 1);
-            pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid);
+            // the counting pass keeps up to stage_cap partners per particle while that costs little LDS
+            for (pc.stage_cap = 16; pc.stage_cap > 0; pc.stage_cap -= 4) {
+                pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap);
+                if (pc.lds_lists <= 24 * 1024 || (size_t)pc.stage_cap * lc.nmax * 2 <= pc.lds_lists / 4) break;
+            }
+            pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap);
             if (pc.lds_lists > h->lds_limit) continue;
             pc.p_begin = s.pk_n;
             pc.entry_base = s.pk_entries;
@@ -849,18 +860,25 @@ int retile(egg_handle *h, int which) {
             }
             s.pk_meta_host.push_back(lc.n_tiles);
             const int per_group = (lc.n_tiles + pc.n_groups - 1) / pc.n_groups;
-            pc.wd = per_group >= 8 ? 8 : per_group >= 3 ? 16 : 64;
+            int max_tiles_in_group = 0;
+            for (int gi = 0; gi < pc.n_groups; ++gi)
+                max_tiles_in_group = std::max(max_tiles_in_group, s.pk_meta_host[pc.meta_grp_tile0 + gi + 1] - s.pk_meta_host[pc.meta_grp_tile0 + gi]);
+            pc.wd = per_group >= 8 ? 8 : 16;
             pc.lds_exec = (size_t)pc.max_group_particles * 16;
-            pc.lds_levels = egg_align16((size_t)(s.pk_lev_cap + 1) * 4) + egg_align16((size_t)pc.max_group_particles * 2);
-            if (pc.lds_exec > h->lds_limit || pc.lds_levels > h->lds_limit) {
+            pc.lds_levels = egg_pk_levels_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd);
+            const size_t group_words = (size_t)max_tiles_in_group * (size_t)pc.scap;
+            pc.chunk_cap = (int)std::min<size_t>(group_words / 64 + (size_t)s.pk_lev_cap + 4, (size_t)1 << 30);
+            if (pc.lds_exec > h->lds_limit || pc.lds_levels > h->lds_limit || group_words >= ((size_t)1 << 26)) {
                 s.pk_meta_host.resize(pc.meta_tile_p0);
                 continue;
             }
+            pc.chunk_base = s.pk_chunk_words;
             lc.packed = (int)s.pk.size();
             s.pk_n = pn;
             s.pk_tiles += lc.n_tiles;
             s.pk_groups += pc.n_groups;
-            s.pk_entries += (size_t)lc.n_tiles * (size_t)lc.lcap;
+            s.pk_entries += (size_t)lc.n_tiles * (size_t)pc.scap;
+            s.pk_chunk_words += (size_t)pc.n_groups * (size_t)pc.chunk_cap;
             s.pk.push_back(pc);
         }
         if (!s.pk.empty()) {
@@ -870,15 +888,13 @@ int retile(egg_handle *h, int which) {
             HIP_TRY(h, s.pk_atom.reserve(np, false, s.stream));
             HIP_TRY(h, s.pk_pos.reserve(2 * np, false, s.stream));
             HIP_TRY(h, s.pk_prev.reserve(2 * np, false, s.stream));
-            HIP_TRY(h, s.pk_vel.reserve(2 * np, false, s.stream));
             HIP_TRY(h, s.pk_wr.reserve(2 * np, false, s.stream));
             HIP_TRY(h, s.pk_ckey.reserve(2 * np, false, s.stream));
-            HIP_TRY(h, s.pk_own_cnt.reserve(np + 8, false, s.stream));
             HIP_TRY(h, s.pk_lists.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_sorted.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_lvl.reserve(s.pk_entries + 64, false, s.stream));
-            HIP_TRY(h, s.pk_levoff.reserve(ng * ((size_t)s.pk_lev_cap + 1) + 64, false, s.stream));
-            HIP_TRY(h, s.pk_nlev.reserve(ng + 4, false, s.stream));
+            HIP_TRY(h, s.pk_chunks.reserve(s.pk_chunk_words + 64, false, s.stream));
+            HIP_TRY(h, s.pk_nchunks.reserve(ng + 4, false, s.stream));
             HIP_TRY(h, s.pk_tile.reserve(nt * (3 + EGG_PK_MAX_PASSES) + 4, false, s.stream));
         }
         s.pk_plan_dirty = true;
@@ -1055,25 +1071,26 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.p_end = pc.p_end;
     A.pk_pos = s.pk_pos.p;
     A.pk_prev = s.pk_prev.p;
-    A.pk_vel = s.pk_vel.p;
     A.pk_wr = s.pk_wr.p;
     A.pk_src = s.pk_src.p;
     A.pk_atom = s.pk_atom.p;
     A.pk_ckey = s.pk_ckey.p;
-    A.pk_own_cnt = s.pk_own_cnt.p;
     A.pk_stride = s.pk_n;
     A.lists = s.pk_lists.p + pc.entry_base;
     A.lvl = s.pk_lvl.p + pc.entry_base;
     A.sorted = s.pk_sorted.p + pc.entry_base;
-    A.lev_off = s.pk_levoff.p + (size_t)pc.group_base * ((size_t)s.pk_lev_cap + 1);
-    A.grp_nlev = s.pk_nlev.p + pc.group_base;
+    A.chunks = s.pk_chunks.p + pc.chunk_base;
+    A.grp_nchunks = s.pk_nchunks.p + pc.group_base;
     int32_t *tb = s.pk_tile.p + (size_t)pc.tile_base * (3 + EGG_PK_MAX_PASSES);
     A.tile_total = tb;
     A.tile_maxlist = tb + pc.n_tiles;
     A.tile_slack = tb + 2 * (size_t)pc.n_tiles;
     A.tile_visits = tb + 3 * (size_t)pc.n_tiles;
     A.lcap = pc.lcap;
+    A.scap = pc.scap;
     A.lev_cap = s.pk_lev_cap;
+    A.chunk_cap = pc.chunk_cap;
+    A.stage_cap = pc.stage_cap;
     A.nmax = lc.nmax;
     A.amax = lc.amax;
     A.ccap = lc.ccap;
@@ -1138,10 +1155,11 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
                        [](const PackedClass &pc) { return pc.lds_exec; });
         }
     }
-    launch_all([](const PackedClass &) { return egg_pk_end_kernel; }, tiles_of, c256, no_lds);
+    launch_all([](const PackedClass &) { return egg_pk_end_kernel; }, tiles_of,
+               [](const PackedClass &pc) { return std::min(256, pc.threads_lists); }, no_lds);
     const int n_passes = std::min(S * C, EGG_PK_MAX_PASSES);
     for (size_t k = 0; k < s.pk.size(); ++k) {
-        hipLaunchKernelGGL(egg_pk_reduce_kernel, dim3(1), dim3(256), 0, st, args[k], n_passes);
+        hipLaunchKernelGGL(egg_pk_reduce_kernel, dim3((unsigned)n_passes + 1), dim3(1024), 0, st, args[k], n_passes);
         h->stats.kernel_launches++;
     }
     HIP_TRY(h, hipGetLastError());

@@ -160,13 +160,28 @@ __device__ __forceinline__ void pk_pre_follow(const EggPackedArgs &A, double2 ps
     out = make_double2(x, y);
 }
 
-// inclusive prefix maximum over the WD consecutive lanes of a sub-wave (sl = lane inside it)
+// inclusive prefix maximum over the WD consecutive lanes of a sub-wave (sl = lane inside it; WD = 8, 16 or 64), with
+// data-parallel-primitive moves: row_shr inside the rows of 16 lanes (masked where a move would cross into the
+// neighbouring sub-wave), row broadcasts for the whole wave
+#define EGG_NEG_LEVEL (-0x40000000)
 template <int WD>
 __device__ __forceinline__ int subwave_incl_max(int v, int sl) {
-#pragma unroll
-    for (int s = 1; s < WD; s <<= 1) {
-        const int o = __shfl_up(v, s, WD);
-        if (sl >= s) v = max(v, o);
+    int t;
+    t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v = max(v, sl >= 1 ? t : EGG_NEG_LEVEL);
+    t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v = max(v, sl >= 2 ? t : EGG_NEG_LEVEL);
+    t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v = max(v, sl >= 4 ? t : EGG_NEG_LEVEL);
+    if (WD > 8) {
+        t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+        v = max(v, (sl & 15) >= 8 ? t : EGG_NEG_LEVEL);
+    }
+    if (WD > 16) {
+        t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+        v = max(v, t);
+        t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+        v = max(v, t);
     }
     return v;
 }
@@ -209,7 +224,6 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_begin_kernel(EggPackedA
     double2 out;
     pk_pre_follow(A, ps, v, wr.x, A.atom_tx[atom], A.atom_ty[atom], A.atom_fd[atom], out);
     ((double2 *)A.pk_prev)[p] = ps;
-    ((double2 *)A.pk_vel)[p] = v;
     ((double2 *)A.pk_pos)[p] = out;
     ((double2 *)A.pk_wr)[p] = wr;
 }
@@ -224,8 +238,7 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_mid_kernel(EggPackedArg
     const double im = ((const double2 *)A.pk_wr)[p].x;
     double2 out;
     pk_pre_follow(A, ps, v, im, A.atom_tx[atom], A.atom_ty[atom], A.atom_fd[atom], out);
-    ((double2 *)A.pk_prev)[p] = ps;
-    ((double2 *)A.pk_vel)[p] = v;
+    ((double2 *)A.pk_prev)[p] = ps;  // (the velocity itself is never stored: post-solve recomputes it from the two positions)
     ((double2 *)A.pk_pos)[p] = out;
 }
 
@@ -239,6 +252,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     if (tile >= A.n_tiles) return;
     Tile t;
     uint32_t *own_off, *tmp;
+    uint16_t *stage;  // [n][stage_cap] partners found by the counting pass, so that the fill does not enumerate again
     {
         const size_t n = (size_t)A.nmax, a = (size_t)A.amax, cc = (size_t)A.ccap;
         unsigned char *p = smem;
@@ -256,6 +270,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
         t.hitems_b = (uint16_t *)carve(p, 2 * n * 2);
         t.pslot = (uint16_t *)carve(p, n * 2);
         t.aslot = (uint16_t *)carve(p, n * 2);
+        stage = A.stage_cap > 0 ? (uint16_t *)carve(p, (size_t)A.stage_cap * n * 2) : nullptr;
         t.s_n = (int)n;
         t.s_c = (int)cc;
         t.s_o = 0;
@@ -354,9 +369,15 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
         ctx.prev_uncut = 1;  // the budget never cuts a multi-tile pass (the host checks the visit counts afterwards)
         ctx.cut_mask = 0;
 
-        // ---------------------------------------- visit lists: count, offsets, fill
-        for (int i = tid; i < n; i += nthreads)
-            t.fill[i] = STALE ? (uint32_t)enum_stale<0>(t, ctx, i, nullptr) : (uint32_t)enum_fresh<false>(t, cur, i, nullptr);
+        // ---------------------------------------- visit lists: count (keeping what is found), offsets
+        const int SC = A.stage_cap;
+        for (int i = tid; i < n; i += nthreads) {
+            uint16_t *slots = stage + (size_t)i * SC;
+            auto keep = [&](int k, int j) {
+                if (k < SC) slots[k] = (uint16_t)j;
+            };
+            t.fill[i] = STALE ? (uint32_t)pk_visit_stale(t, ctx, i, keep) : (uint32_t)pk_visit_fresh(t, cur, i, keep);
+        }
         __syncthreads();
         block_exclusive_scan<false>(t.fill, own_off, n, tid, nthreads, wtot);
         __syncthreads();
@@ -368,16 +389,17 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
         if (!fits) atomicExch(&A.status->fail_overflow, 1);
         const int before = A.pass_seq == 0 ? 0 : A.tile_maxlist[tile];
         A.tile_maxlist[tile] = max(before, total);  // what the pass needs, even when it does not fit
-        A.tile_total[tile] = fits ? total : 0;
+        // a tile that failed a check gets an empty stream: the later phases then leave it alone (the step is re-run)
+        A.tile_total[tile] = (fits && !any_bad) ? total : 0;
     }
-    // a tile that failed a check gets empty lists: the later phases then leave it alone (the step is re-run)
-    const bool emit_lists = !any_bad && fits;
-    uint32_t *glist = A.lists + (size_t)tile * A.lcap;
-    for (int i = tid; i < n; i += nthreads) {
-        int cnt = 0;
-        if (emit_lists) {
+    // ---------------------------------------- the tile's pair stream: the visit entries of every self, in order
+    if (!any_bad && fits) {
+        uint32_t *gstream = A.lists + (size_t)tile * A.scap;
+        const int SC = A.stage_cap;
+        for (int i = tid; i < n; i += nthreads) {
+            const int cnt = (int)t.fill[i];
+            uint32_t *dst = gstream + own_off[i];
             const double2 wi = t.wr[i];
-            uint32_t *dst = glist + own_off[i];
             auto emit = [&](int k, int j) {
                 const double2 wj = t.wr[j];
                 const bool slow = pair_needs_reference(wi, wj, A.overlap_factor, A.collision_compliance, A.eps);
@@ -385,17 +407,23 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
                 if (slow && wi.x + wj.x < A.eps) ++guarded;
                 dst[k] = (uint32_t)i | (slow ? 0x8000u : 0u) | ((uint32_t)j << 16);
             };
-            PassCtx ctx;
-            ctx.cur = cur;
-            ctx.prev = prev;
-            ctx.live = STALE ? 1 : 0;
-            ctx.G = 2;
-            ctx.stale = STALE ? 1 : 0;
-            ctx.prev_uncut = 1;
-            ctx.cut_mask = 0;
-            cnt = STALE ? pk_visit_stale(t, ctx, i, emit) : pk_visit_fresh(t, cur, i, emit);
+            if (cnt <= SC) {
+                const uint16_t *slots = stage + (size_t)i * SC;
+                for (int k = 0; k < cnt; ++k) emit(k, (int)slots[k]);
+            } else if (STALE) {
+                PassCtx ctx;
+                ctx.cur = cur;
+                ctx.prev = prev;
+                ctx.live = 1;
+                ctx.G = 2;
+                ctx.stale = 1;
+                ctx.prev_uncut = 1;
+                ctx.cut_mask = 0;
+                pk_visit_stale(t, ctx, i, emit);
+            } else {
+                pk_visit_fresh(t, cur, i, emit);
+            }
         }
-        A.pk_own_cnt[p0 + i] = (uint16_t)cnt;
     }
     // n_collided of this tile and pass: visited pairs that passed the mass guard
 #pragma unroll
@@ -405,19 +433,22 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     if (tid == 0) {
         uint32_t gsum = 0;
         for (int w = 0; w < (nthreads + 63) / 64; ++w) gsum += wtot[w];
-        A.tile_visits[(size_t)min(A.pass_seq, EGG_PK_MAX_PASSES - 1) * A.n_tiles + tile] = emit_lists ? total - (int)gsum : 0;
+        A.tile_visits[(size_t)min(A.pass_seq, EGG_PK_MAX_PASSES - 1) * A.n_tiles + tile] =
+            (fits && !any_bad) ? total - (int)gsum : 0;
     }
 }
 extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_fresh_kernel(EggPackedArgs A) { egg_pk_lists_body<false>(A); }
 extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_stale_kernel(EggPackedArgs A) { egg_pk_lists_body<true>(A); }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 2: levels.  One wave per group; a sub-wave of WD lanes walks one tile's pair sequence.
+// Phase 2: levels.  One wave per group; a sub-wave of WD lanes walks one tile's pair stream.
 //
 // Sequential definition: for the pairs e = (a, b) in the reference's order, level(e) = 1 + max(last[a], last[b]),
-// then last[a] = last[b] = level(e).  The run of one self a (partners b_0 .. b_m-1, all different, none equal
-// to a) gives  l_k = max(l_{k-1}, last[b_k]) + 1  with l_{-1} = last[a], i.e.
+// then last[a] = last[b] = level(e).  A run of one self a (partners b_0 .. b_m-1, all different, none equal to
+// a) gives  l_k = max(l_{k-1}, last[b_k]) + 1  with l_{-1} = last[a], i.e.
 // l_k = k + 1 + max(last[a], max_{j <= k}(last[b_j] - j)): a prefix maximum over the lanes of the sub-wave.
+// The stream is read through a small LDS window per sub-wave (one coalesced refill per EGG_PK_WINDOW words),
+// so the walk itself never waits for global memory.
 template <int WD>
 __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -427,49 +458,65 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
     const int t0 = A.grp_tile0[g], t1 = A.grp_tile0[g + 1];
     const int p0 = A.tile_p0[t0], np = A.tile_p0[t1] - p0;
     const int lev_cap = A.lev_cap;
-    uint32_t *hist = (uint32_t *)smem;                       // [lev_cap + 1] pairs per level, then the running fill offsets
-    uint16_t *last = (uint16_t *)(smem + egg_align16((size_t)(lev_cap + 1) * 4));  // [np] level of the last pair of each particle
-    for (int i = lane; i <= lev_cap; i += 64) hist[i] = 0;
+    constexpr int NSUB = 64 / WD, W = EGG_PK_WINDOW;
+    uint32_t *hist = (uint32_t *)smem;  // [lev_cap + 2] pairs per level, later the running fill offsets
+    uint16_t *last = (uint16_t *)(smem + egg_align16((size_t)(lev_cap + 2) * 4));  // [np] level of each particle's last pair
+    uint32_t *win_all = (uint32_t *)(smem + egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)np * 2));
+    for (int i = lane; i <= lev_cap + 1; i += 64) hist[i] = 0;
     for (int i = lane; i < np; i += 64) last[i] = 0;
     // (one wave: its LDS operations execute in issue order, no barrier needed)
     const int sub = lane / WD, sl = lane % WD;
-    constexpr int NSUB = 64 / WD;
+    uint32_t *win = win_all + sub * W;
     int maxlev = 0;
     bool over = false;
     for (int ti = t0 + sub; ti < t1; ti += NSUB) {
-        const int tp0 = A.tile_p0[ti], n = A.tile_p0[ti + 1] - tp0, base = tp0 - p0;
-        const uint32_t *list = A.lists + (size_t)ti * A.lcap;
-        uint16_t *lv = A.lvl + (size_t)ti * A.lcap;
-        const int total = A.tile_total[ti];
-        int off = 0;
-        for (int a = 0; a < n && off < total; ++a) {
-            const int cnt = (int)A.pk_own_cnt[tp0 + a];
-            if (cnt == 0) continue;
-            int x0 = (int)last[base + a];
-            for (int k0 = 0; k0 < cnt; k0 += WD) {
-                const int k = k0 + sl;
-                const bool valid = k < cnt;
-                const uint32_t rec = valid ? list[off + k] : 0u;
-                const int b = (int)((rec >> 16) & 0x7FFFu);
-                const int c = valid ? (int)last[base + b] : 0;
-                const int d = valid ? c - sl : -0x40000000;
-                const int pm = subwave_incl_max<WD>(d, sl);
-                int l = sl + 1 + max(x0, pm);
-                if (l > lev_cap) {  // deeper than the level table: report what is needed, keep the tables in range
-                    over = true;
-                    maxlev = max(maxlev, l);
-                    l = lev_cap;
-                }
-                if (valid) {
-                    last[base + b] = (uint16_t)l;
-                    lv[off + k] = (uint16_t)l;
-                    atomicAdd(&hist[l], 1u);
-                }
-                x0 = __shfl(l, min(cnt - k0, WD) - 1, WD);
+        const int tp0 = A.tile_p0[ti], base = tp0 - p0;
+        const uint32_t *stream = A.lists + (size_t)ti * A.scap;
+        uint16_t *lv = A.lvl + (size_t)ti * A.scap;
+        const int slen = A.tile_total[ti];
+        // One turn = the next (at most WD) entries of ONE self: the entries of a self are contiguous and carry it, so
+        // the run's length inside the window is found with a ballot; last[self] is re-read from LDS every turn, which
+        // also chains the pieces of a run longer than WD.  No branch depends on the run structure.
+        int q = 0, wlen = 0, r = 0;
+        while (q + r < slen) {
+            if (r + WD > wlen && q + wlen < slen) {  // fewer than WD entries left in the window and more in the stream
+                q += r;
+                r = 0;
+                wlen = min(W, slen - q);
+                for (int x = sl; x < wlen; x += WD) win[x] = stream[q + x];
             }
-            if (sl == 0) last[base + a] = (uint16_t)x0;
-            maxlev = max(maxlev, x0);
-            off += cnt;
+            const int avail = wlen - r;  // >= 1
+            const uint32_t rec = (sl < avail) ? win[r + sl] : 0xFFFFFFFFu;
+            const uint32_t a0 = win[r] & 0x7FFFu;
+            // m = entries of this turn: the leading lanes whose self is a0
+            const unsigned long long differs = __ballot((rec & 0x7FFFu) != a0 || sl >= avail);
+            int m;
+            if (WD == 64) {
+                m = differs ? (int)__builtin_ctzll(differs) : 64;
+            } else {
+                const uint32_t mine = (uint32_t)(differs >> (sub * WD)) & ((1u << (WD & 31)) - 1u);
+                m = mine ? (int)__builtin_ctz(mine) : WD;
+            }
+            const bool valid = sl < m;
+            const int b = (int)((rec >> 16) & 0x7FFFu);
+            const int c = valid ? (int)last[base + b] : 0;
+            const int xa = (int)last[base + (int)a0];
+            const int d = valid ? c - sl : EGG_NEG_LEVEL;
+            const int pm = subwave_incl_max<WD>(d, sl);
+            int l = sl + 1 + max(xa, pm);
+            if (valid && l > lev_cap) {  // deeper than the level table: report what is needed, keep the tables in range
+                over = true;
+                maxlev = max(maxlev, l);
+                l = lev_cap;
+            }
+            if (valid) {
+                last[base + b] = (uint16_t)l;
+                lv[q + r + sl] = (uint16_t)l;
+                atomicAdd(&hist[l], 1u);
+                maxlev = max(maxlev, l);
+                if (sl == m - 1) last[base + (int)a0] = (uint16_t)l;
+            }
+            r += m;
         }
     }
 #pragma unroll
@@ -480,34 +527,47 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
         atomicMax(&A.status->max_level, maxlev);
     }
     const int nlev = min(maxlev, lev_cap);
-    // offsets of the levels inside the group's sorted list: exclusive scan of the histogram (level 0 is empty)
-    uint32_t *goff = A.lev_off + (size_t)g * (lev_cap + 1);
-    uint32_t carry = 0;
-    for (int b0 = 0; b0 <= nlev; b0 += 64) {
+    // start of every level inside the group's sorted list (exclusive scan of the histogram; level 0 is empty), and
+    // the executor's work list: chunks of at most 64 pairs, each inside one level, levels ascending
+    uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
+    uint32_t carry = 0, ccarry = 0;
+    for (int b0 = 1; b0 <= nlev; b0 += 64) {
         const int L = b0 + lane;
         const uint32_t v = (L <= nlev) ? hist[L] : 0u;
-        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane);
-        const uint32_t excl = carry + incl - v;
+        const uint32_t nch = (v + 63u) >> 6;
+        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane), cincl = (uint32_t)wave_incl_scan((int)nch, lane);
+        const uint32_t start = carry + incl - v, cb = ccarry + cincl - nch;
         if (L <= nlev) {
-            // goff[L] = end of level L (= start of level L + 1); level L's pairs are [goff[L - 1], goff[L])
-            goff[L] = excl + v;
-            hist[L] = excl;
+            hist[L] = start;
+            for (uint32_t c = 0; c < nch; ++c)
+                if (cb + c < (uint32_t)A.chunk_cap) chunks[cb + c] = (start + 64u * c) | ((min(64u, v - 64u * c) - 1u) << 26);
         }
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        ccarry += (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
     }
-    if (lane == 0) A.grp_nlev[g] = over ? 0 : nlev;  // an overflowed group is left alone by the executor (the step is re-run)
-    // counting sort: every pair to its level's slot range, indices made group-local
-    uint32_t *sorted = A.sorted + (size_t)t0 * A.lcap;
+    // an overflowed group is left alone by the executor (the step is re-run with larger tables)
+    if (lane == 0) A.grp_nchunks[g] = (over || ccarry > (uint32_t)A.chunk_cap) ? 0 : (int)ccarry;
+    // counting sort: every pair to its level's slot range, indices made group-local; bit 31 marks a pair
+    uint32_t *sorted = A.sorted + (size_t)t0 * A.scap;
     for (int ti = t0; ti < t1; ++ti) {
         const uint32_t base = (uint32_t)(A.tile_p0[ti] - p0);
-        const uint32_t *list = A.lists + (size_t)ti * A.lcap;
-        const uint16_t *lv = A.lvl + (size_t)ti * A.lcap;
-        const int total = A.tile_total[ti];
-        for (int e = lane; e < total; e += 64) {
-            const uint32_t rec = list[e];
-            const uint32_t l = lv[e];
-            const uint32_t pos = atomicAdd(&hist[l], 1u);
-            sorted[pos] = ((rec & 0x7FFFu) + base) | (rec & 0x8000u) | ((((rec >> 16) & 0x7FFFu) + base) << 16);
+        const uint32_t *stream = A.lists + (size_t)ti * A.scap;
+        const uint16_t *lv = A.lvl + (size_t)ti * A.scap;
+        const int slen = A.tile_total[ti];
+        for (int e0 = 0; e0 < slen; e0 += 256) {
+            uint32_t rec[4], l[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 64 * u + lane;
+                rec[u] = (e < slen) ? stream[e] : 0u;
+                l[u] = (e < slen) ? (uint32_t)lv[e] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + 64 * u + lane < slen) {
+                    const uint32_t pos = atomicAdd(&hist[l[u]], 1u);
+                    sorted[pos] = 0x80000000u | ((rec[u] & 0x7FFFu) + base) | (rec[u] & 0x8000u) | ((((rec[u] >> 16) & 0x7FFFu) + base) << 16);
+                }
         }
     }
 }
@@ -516,41 +576,61 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_levels16_kernel(EggPacke
 extern "C" __global__ void __launch_bounds__(64) egg_pk_levels64_kernel(EggPackedArgs A) { egg_pk_levels_body<64>(A); }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 3: the pair projections (L:1514-1545, L:1632-1654), level by level, 64 pairs per wave-instruction.
+// Phase 3: the pair projections (L:1514-1545, L:1632-1654), chunk after chunk: at most 64 pairs of one level per
+// wave-instruction.  The work list is static, so the loads of the next chunks run ahead of the arithmetic: the
+// entries two chunks ahead, the (inverse mass, radius) records of both particles one chunk ahead; only the
+// positions are read when they are needed -- from LDS.
 extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *lpos = (double2 *)smem;
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
     const int lane = threadIdx.x;
+    const int nch = A.grp_nchunks[g];
+    if (nch <= 0) return;  // nothing to do: positions stay as they are
     const int t0 = A.grp_tile0[g], t1 = A.grp_tile0[g + 1];
     const int p0 = A.tile_p0[t0], np = A.tile_p0[t1] - p0;
-    const int nlev = A.grp_nlev[g];
-    if (nlev <= 0) return;  // nothing to do: positions stay as they are
     double2 *gpos = (double2 *)A.pk_pos + p0;
     const double2 *gwr = (const double2 *)A.pk_wr + p0;
     for (int i = lane; i < np; i += 64) lpos[i] = gpos[i];
-    const uint32_t *sorted = A.sorted + (size_t)t0 * A.lcap;
-    const uint32_t *goff = A.lev_off + (size_t)g * (A.lev_cap + 1);
+    const uint32_t *sorted = A.sorted + (size_t)t0 * A.scap;
+    const uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
     const double overlap = A.overlap_factor, compliance = A.collision_compliance, eps = A.eps;
-    uint32_t start = 0;
-    for (int L = 1; L <= nlev; ++L) {
-        const uint32_t end = goff[L];
-        for (uint32_t e0 = start; e0 < end; e0 += 64) {
-            const uint32_t e = e0 + (uint32_t)lane;
-            if (e < end) {
-                const uint32_t rec = sorted[e];
-                const int ga = (int)(rec & 0x7FFFu), gb = (int)((rec >> 16) & 0x7FFFu);
-                double2 pa = lpos[ga], pb = lpos[gb];
-                const double2 wra = gwr[ga], wrb = gwr[gb];
-                project_pair<false>(
-                    [&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
-                    (rec & 0x8000u) != 0, pa, pb, wra, wrb, wra, overlap, compliance, eps);
-                lpos[ga] = pa;
-                lpos[gb] = pb;
-            }
+    // chunk descriptors: 64 at a time in a register, picked out with readlane
+    uint32_t dreg = (lane < nch) ? chunks[lane] : 0u;
+    auto load_rec = [&](uint32_t desc) -> uint32_t {
+        const uint32_t start = desc & 0x3FFFFFFu, cnt = (desc >> 26) + 1u;
+        return ((uint32_t)lane < cnt) ? sorted[start + (uint32_t)lane] : 0u;  // bit 31 set on real entries
+    };
+    auto desc_of = [&](int c, uint32_t reg) { return (uint32_t)__builtin_amdgcn_readlane((int)reg, c & 63); };
+    // software pipeline: entries three chunks ahead, particle constants two chunks ahead
+    uint32_t rec0 = load_rec(desc_of(0, dreg));
+    uint32_t rec1 = (nch > 1) ? load_rec(desc_of(1, dreg)) : 0u;
+    uint32_t rec2 = (nch > 2) ? load_rec(desc_of(2, dreg)) : 0u;
+    double2 wa0 = gwr[rec0 & 0x7FFFu], wb0 = gwr[(rec0 >> 16) & 0x7FFFu];
+    double2 wa1 = gwr[rec1 & 0x7FFFu], wb1 = gwr[(rec1 >> 16) & 0x7FFFu];
+    for (int c = 0; c < nch; ++c) {
+        uint32_t rec3 = 0u;
+        if (c + 3 < nch) {
+            if (((c + 3) & 63) == 0) dreg = (c + 3 + lane < nch) ? chunks[c + 3 + lane] : 0u;  // next block of descriptors
+            rec3 = load_rec(desc_of(c + 3, dreg));
         }
-        start = end;
+        const double2 wa2 = gwr[rec2 & 0x7FFFu], wb2 = gwr[(rec2 >> 16) & 0x7FFFu];
+        if (rec0 >> 31) {
+            const int ga = (int)(rec0 & 0x7FFFu), gb = (int)((rec0 >> 16) & 0x7FFFu);
+            double2 pa = lpos[ga], pb = lpos[gb];
+            project_pair<false>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
+                                (rec0 & 0x8000u) != 0, pa, pb, wa0, wb0, wa0, overlap, compliance, eps);
+            lpos[ga] = pa;
+            lpos[gb] = pb;
+        }
+        rec0 = rec1;
+        rec1 = rec2;
+        rec2 = rec3;
+        wa0 = wa1;
+        wb0 = wb1;
+        wa1 = wa2;
+        wb1 = wb2;
     }
     for (int i = lane; i < np; i += 64) gpos[i] = lpos[i];
 }
@@ -636,25 +716,38 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_end_kernel(EggPackedArg
     }
 }
 
-// One workgroup: the per-tile counters of the class become the step's status entries (one atomic each instead of
-// one per tile: thousands of same-address atomics would serialise at ~12 ns apiece).
-extern "C" __global__ void __launch_bounds__(256) egg_pk_reduce_kernel(EggPackedArgs A, int n_passes) {
-    __shared__ long long wsum[4];
-    __shared__ int wmin[4], wmax[4];
-    const int tid = threadIdx.x;
-    for (int ps = 0; ps < n_passes; ++ps) {
+// The per-tile counters of the class become the step's status entries: one atomic per workgroup instead of one per
+// tile (thousands of same-address atomics would serialise at ~12 ns apiece).  Block b < n_passes sums the visits of
+// pass b; the last block reduces slack and list sizes.
+extern "C" __global__ void __launch_bounds__(1024) egg_pk_reduce_kernel(EggPackedArgs A, int n_passes) {
+    __shared__ long long wsum[16];
+    __shared__ int wmin[16], wmax[16];
+    const int tid = threadIdx.x, ps = blockIdx.x;
+    if (ps < n_passes) {
         long long s = 0;
         const int32_t *v = A.tile_visits + (size_t)ps * A.n_tiles;
-        for (int t = tid; t < A.n_tiles; t += 256) s += v[t];
+        for (int t0 = 0; t0 < A.n_tiles; t0 += 4096) {
+            int x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 1024 * u + tid;
+                x[u] = (t < A.n_tiles) ? v[t] : 0;
+            }
+            s += (long long)x[0] + x[1] + x[2] + x[3];
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-        __syncthreads();
         if ((tid & 63) == 0) wsum[tid >> 6] = s;
         __syncthreads();
-        if (tid == 0) atomicAdd(&A.status->visits[ps], (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+        if (tid == 0) {
+            long long tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            atomicAdd(&A.status->visits[ps], (unsigned long long)tot);
+        }
+        return;
     }
     int slack = 0x7FFFFFFF, ml = 0;
-    for (int t = tid; t < A.n_tiles; t += 256) {
+    for (int t = tid; t < A.n_tiles; t += 1024) {
         slack = min(slack, A.tile_slack[t]);
         ml = max(ml, A.tile_maxlist[t]);
     }
@@ -669,7 +762,11 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_reduce_kernel(EggPacked
     }
     __syncthreads();
     if (tid == 0) {
-        atomicMin(&A.status->min_slack, min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3])));
-        atomicMax(&A.status->max_list, (unsigned long long)max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+        for (int w = 1; w < 16; ++w) {
+            slack = min(slack, wmin[w]);
+            ml = max(ml, wmax[w]);
+        }
+        atomicMin(&A.status->min_slack, min(slack, wmin[0]));
+        atomicMax(&A.status->max_list, (unsigned long long)max(ml, wmax[0]));
     }
 }

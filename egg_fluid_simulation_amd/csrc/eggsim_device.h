@@ -150,6 +150,8 @@ struct EggPackedArgs {
     uint32_t *chunks;          // [n_groups][chunk_cap] the executor's work list: start | (count - 1) << 26 into `sorted`,
                                // every chunk inside one level, levels ascending
     int32_t *grp_nchunks;      // [n_groups]
+    uint32_t *lev_start;       // [n_groups][lev_cap + 2] first slot of every level in the group's sorted list
+    int32_t *grp_nlev;         // [n_groups]
     int32_t *tile_total;       // [n_tiles] visit entries of the current pass
     int32_t *tile_visits;      // [EGG_PK_MAX_PASSES][n_tiles] n_collided of each pass (L:1657)
     int32_t *tile_maxlist;     // [n_tiles] largest list of the step

@@ -47,6 +47,7 @@ extern "C" __global__ void egg_pk_levels8_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels16_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels64_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_exec_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_sort_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_end_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_reduce_kernel(EggPackedArgs A, int n_passes);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
@@ -226,7 +227,7 @@ struct System {  // one particle type
     std::vector<int32_t> pk_meta_host;       // tile_p0 / grp_tile0 of every packed class
     DevBuf<int32_t> pk_meta, pk_src, pk_atom, pk_tile, pk_nchunks;
     DevBuf<double> pk_pos, pk_prev, pk_wr;
-    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_chunks;
+    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_chunks, pk_levstart;
     DevBuf<uint16_t> pk_lvl;
     int pk_n = 0, pk_tiles = 0, pk_groups = 0;
     size_t pk_entries = 0;                   // stream words over all packed tiles
@@ -894,7 +895,8 @@ int retile(egg_handle *h, int which) {
             HIP_TRY(h, s.pk_sorted.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_lvl.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_chunks.reserve(s.pk_chunk_words + 64, false, s.stream));
-            HIP_TRY(h, s.pk_nchunks.reserve(ng + 4, false, s.stream));
+            HIP_TRY(h, s.pk_nchunks.reserve(2 * ng + 8, false, s.stream));
+            HIP_TRY(h, s.pk_levstart.reserve(ng * ((size_t)s.pk_lev_cap + 2) + 64, false, s.stream));
             HIP_TRY(h, s.pk_tile.reserve(nt * (3 + EGG_PK_MAX_PASSES) + 4, false, s.stream));
         }
         s.pk_plan_dirty = true;
@@ -1081,6 +1083,8 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.sorted = s.pk_sorted.p + pc.entry_base;
     A.chunks = s.pk_chunks.p + pc.chunk_base;
     A.grp_nchunks = s.pk_nchunks.p + pc.group_base;
+    A.grp_nlev = s.pk_nchunks.p + s.pk_groups + pc.group_base;
+    A.lev_start = s.pk_levstart.p + (size_t)pc.group_base * ((size_t)s.pk_lev_cap + 2);
     int32_t *tb = s.pk_tile.p + (size_t)pc.tile_base * (3 + EGG_PK_MAX_PASSES);
     A.tile_total = tb;
     A.tile_maxlist = tb + pc.n_tiles;
@@ -1151,6 +1155,8 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
                            return pc.wd == 8 ? egg_pk_levels8_kernel : pc.wd == 16 ? egg_pk_levels16_kernel : egg_pk_levels64_kernel;
                        },
                        groups_of, c64, [](const PackedClass &pc) { return pc.lds_levels; });
+            launch_all([](const PackedClass &) { return egg_pk_sort_kernel; }, groups_of, c256,
+                       [&](const PackedClass &) { return egg_align16((size_t)(s.pk_lev_cap + 2) * 4); });
             launch_all([](const PackedClass &) { return egg_pk_exec_kernel; }, groups_of, c64,
                        [](const PackedClass &pc) { return pc.lds_exec; });
         }

@@ -477,17 +477,36 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
         // One turn = the next (at most WD) entries of ONE self: the entries of a self are contiguous and carry it, so
         // the run's length inside the window is found with a ballot; last[self] is re-read from LDS every turn, which
         // also chains the pieces of a run longer than WD.  No branch depends on the run structure.
+        // The window is refilled from registers: the words any next window can need ([q + W - WD, q + 2 W)) are
+        // requested as soon as a window is in place, a whole window's walk ahead of their use.
+        constexpr int PF = (W + WD) / WD;
+        uint32_t pf[PF];
+        int pf_base = 0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) pf[u] = stream[min(sl + WD * u, max(slen - 1, 0))];
         int q = 0, wlen = 0, r = 0;
         while (q + r < slen) {
             if (r + WD > wlen && q + wlen < slen) {  // fewer than WD entries left in the window and more in the stream
                 q += r;
                 r = 0;
                 wlen = min(W, slen - q);
-                for (int x = sl; x < wlen; x += WD) win[x] = stream[q + x];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int pos = pf_base + sl + WD * u - q;
+                    if (pos >= 0 && pos < W) win[pos] = pf[u];
+                }
+                pf_base = q + W - WD;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) pf[u] = stream[min(pf_base + sl + WD * u, slen - 1)];
             }
             const int avail = wlen - r;  // >= 1
-            const uint32_t rec = (sl < avail) ? win[r + sl] : 0xFFFFFFFFu;
+            const uint32_t rec = (sl < avail) ? win[r + sl] : 0u;
             const uint32_t a0 = win[r] & 0x7FFFu;
+            const int b = (int)((rec >> 16) & 0x7FFFu);
+            // both level reads go out together, before the run length is known (lanes beyond the run read the level
+            // of some other pair's partner and drop it)
+            const int c_raw = (int)last[base + b];
+            const int xa = (int)last[base + (int)a0];
             // m = entries of this turn: the leading lanes whose self is a0
             const unsigned long long differs = __ballot((rec & 0x7FFFu) != a0 || sl >= avail);
             int m;
@@ -498,10 +517,7 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
                 m = mine ? (int)__builtin_ctz(mine) : WD;
             }
             const bool valid = sl < m;
-            const int b = (int)((rec >> 16) & 0x7FFFu);
-            const int c = valid ? (int)last[base + b] : 0;
-            const int xa = (int)last[base + (int)a0];
-            const int d = valid ? c - sl : EGG_NEG_LEVEL;
+            const int d = valid ? c_raw - sl : EGG_NEG_LEVEL;
             const int pm = subwave_incl_max<WD>(d, sl);
             int l = sl + 1 + max(xa, pm);
             if (valid && l > lev_cap) {  // deeper than the level table: report what is needed, keep the tables in range
@@ -530,6 +546,7 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
     // start of every level inside the group's sorted list (exclusive scan of the histogram; level 0 is empty), and
     // the executor's work list: chunks of at most 64 pairs, each inside one level, levels ascending
     uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
+    uint32_t *lstart = A.lev_start + (size_t)g * (lev_cap + 2);
     uint32_t carry = 0, ccarry = 0;
     for (int b0 = 1; b0 <= nlev; b0 += 64) {
         const int L = b0 + lane;
@@ -538,42 +555,62 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
         const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane), cincl = (uint32_t)wave_incl_scan((int)nch, lane);
         const uint32_t start = carry + incl - v, cb = ccarry + cincl - nch;
         if (L <= nlev) {
-            hist[L] = start;
+            lstart[L] = start;
             for (uint32_t c = 0; c < nch; ++c)
                 if (cb + c < (uint32_t)A.chunk_cap) chunks[cb + c] = (start + 64u * c) | ((min(64u, v - 64u * c) - 1u) << 26);
         }
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         ccarry += (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
     }
-    // an overflowed group is left alone by the executor (the step is re-run with larger tables)
-    if (lane == 0) A.grp_nchunks[g] = (over || ccarry > (uint32_t)A.chunk_cap) ? 0 : (int)ccarry;
-    // counting sort: every pair to its level's slot range, indices made group-local; bit 31 marks a pair
+    // an overflowed group is left alone by the later phases (the step is re-run with larger tables)
+    const bool usable = !over && ccarry <= (uint32_t)A.chunk_cap;
+    if (lane == 0) {
+        A.grp_nchunks[g] = usable ? (int)ccarry : 0;
+        A.grp_nlev[g] = usable ? nlev : 0;
+    }
+}
+extern "C" __global__ void __launch_bounds__(64) egg_pk_levels8_kernel(EggPackedArgs A) { egg_pk_levels_body<8>(A); }
+extern "C" __global__ void __launch_bounds__(64) egg_pk_levels16_kernel(EggPackedArgs A) { egg_pk_levels_body<16>(A); }
+extern "C" __global__ void __launch_bounds__(64) egg_pk_levels64_kernel(EggPackedArgs A) { egg_pk_levels_body<64>(A); }
+
+// Phase 2b: counting sort of a group's pairs by level (one workgroup per group: the walk above is one wave, this
+// part has no dependencies and wants many loads in flight).  Indices become group-local; bit 31 marks a pair.
+extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_kernel(EggPackedArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *cursor = (uint32_t *)smem;  // [nlev + 1] next free slot of every level
+    const int g = blockIdx.x;
+    if (g >= A.n_groups) return;
+    const int tid = threadIdx.x;
+    const int nlev = A.grp_nlev[g];
+    if (nlev <= 0) return;
+    const int t0 = A.grp_tile0[g], t1 = A.grp_tile0[g + 1];
+    const int p0 = A.tile_p0[t0];
+    const uint32_t *lstart = A.lev_start + (size_t)g * (A.lev_cap + 2);
+    for (int L = 1 + tid; L <= nlev; L += 256) cursor[L] = lstart[L];
+    __syncthreads();
     uint32_t *sorted = A.sorted + (size_t)t0 * A.scap;
     for (int ti = t0; ti < t1; ++ti) {
         const uint32_t base = (uint32_t)(A.tile_p0[ti] - p0);
         const uint32_t *stream = A.lists + (size_t)ti * A.scap;
         const uint16_t *lv = A.lvl + (size_t)ti * A.scap;
         const int slen = A.tile_total[ti];
-        for (int e0 = 0; e0 < slen; e0 += 256) {
+        for (int e0 = 0; e0 < slen; e0 += 1024) {
             uint32_t rec[4], l[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = e0 + 64 * u + lane;
-                rec[u] = (e < slen) ? stream[e] : 0u;
-                l[u] = (e < slen) ? (uint32_t)lv[e] : 0u;
+                const int e = min(e0 + 256 * u + tid, slen - 1);
+                rec[u] = stream[e];
+                l[u] = (uint32_t)lv[e];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (e0 + 64 * u + lane < slen) {
-                    const uint32_t pos = atomicAdd(&hist[l[u]], 1u);
+                if (e0 + 256 * u + tid < slen) {
+                    const uint32_t pos = atomicAdd(&cursor[l[u]], 1u);
                     sorted[pos] = 0x80000000u | ((rec[u] & 0x7FFFu) + base) | (rec[u] & 0x8000u) | ((((rec[u] >> 16) & 0x7FFFu) + base) << 16);
                 }
         }
     }
 }
-extern "C" __global__ void __launch_bounds__(64) egg_pk_levels8_kernel(EggPackedArgs A) { egg_pk_levels_body<8>(A); }
-extern "C" __global__ void __launch_bounds__(64) egg_pk_levels16_kernel(EggPackedArgs A) { egg_pk_levels_body<16>(A); }
-extern "C" __global__ void __launch_bounds__(64) egg_pk_levels64_kernel(EggPackedArgs A) { egg_pk_levels_body<64>(A); }
 
 // ------------------------------------------------------------------------------------------------
 // Phase 3: the pair projections (L:1514-1545, L:1632-1654), chunk after chunk: at most 64 pairs of one level per
@@ -592,45 +629,59 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
     const int p0 = A.tile_p0[t0], np = A.tile_p0[t1] - p0;
     double2 *gpos = (double2 *)A.pk_pos + p0;
     const double2 *gwr = (const double2 *)A.pk_wr + p0;
-    for (int i = lane; i < np; i += 64) lpos[i] = gpos[i];
+    // the group's positions into LDS: eight loads in flight per lane (a load-wait-store loop pays one memory
+    // round trip per 64 particles)
+    for (int i0 = 0; i0 < np; i0 += 512) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gpos[min(i0 + 64 * u + lane, np - 1)];
+        // (unconditional stores: beyond the end the last particle is stored again -- a conditional store would
+        // pull each load into its own branch and serialise the round trips)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lpos[min(i0 + 64 * u + lane, np - 1)] = v[u];
+    }
     const uint32_t *sorted = A.sorted + (size_t)t0 * A.scap;
     const uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
     const double overlap = A.overlap_factor, compliance = A.collision_compliance, eps = A.eps;
     // chunk descriptors: 64 at a time in a register, picked out with readlane
     uint32_t dreg = (lane < nch) ? chunks[lane] : 0u;
-    auto load_rec = [&](uint32_t desc) -> uint32_t {
+    auto load_rec = [&](int c) -> uint32_t {  // the entries of chunk c (0 beyond the work list); bit 31 set on real entries
+        if (c >= nch) return 0u;
+        if ((c & 63) == 0 && c > 0) dreg = (c + lane < nch) ? chunks[c + lane] : 0u;  // next block of descriptors
+        const uint32_t desc = (uint32_t)__builtin_amdgcn_readlane((int)dreg, c & 63);
         const uint32_t start = desc & 0x3FFFFFFu, cnt = (desc >> 26) + 1u;
-        return ((uint32_t)lane < cnt) ? sorted[start + (uint32_t)lane] : 0u;  // bit 31 set on real entries
+        return ((uint32_t)lane < cnt) ? sorted[start + (uint32_t)lane] : 0u;
     };
-    auto desc_of = [&](int c, uint32_t reg) { return (uint32_t)__builtin_amdgcn_readlane((int)reg, c & 63); };
-    // software pipeline: entries three chunks ahead, particle constants two chunks ahead
-    uint32_t rec0 = load_rec(desc_of(0, dreg));
-    uint32_t rec1 = (nch > 1) ? load_rec(desc_of(1, dreg)) : 0u;
-    uint32_t rec2 = (nch > 2) ? load_rec(desc_of(2, dreg)) : 0u;
-    double2 wa0 = gwr[rec0 & 0x7FFFu], wb0 = gwr[(rec0 >> 16) & 0x7FFFu];
-    double2 wa1 = gwr[rec1 & 0x7FFFu], wb1 = gwr[(rec1 >> 16) & 0x7FFFu];
-    for (int c = 0; c < nch; ++c) {
-        uint32_t rec3 = 0u;
-        if (c + 3 < nch) {
-            if (((c + 3) & 63) == 0) dreg = (c + 3 + lane < nch) ? chunks[c + 3 + lane] : 0u;  // next block of descriptors
-            rec3 = load_rec(desc_of(c + 3, dreg));
+    // Software pipeline over the static work list: the entries of a chunk are requested three chunks ahead, the
+    // (inverse mass, radius) records of its particles two chunks ahead.  The ring of four stages is indexed with
+    // compile-time constants (the loop is unrolled by four), so nothing is copied and no load is waited for
+    // before its chunk is due.
+    uint32_t rec[4];
+    double2 wa[4], wb[4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) rec[u] = load_rec(u);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        wa[u] = gwr[rec[u] & 0x7FFFu];
+        wb[u] = gwr[(rec[u] >> 16) & 0x7FFFu];
+    }
+    for (int c0 = 0; c0 < nch; c0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u;
+            rec[(u + 3) & 3] = load_rec(c + 3);
+            wa[(u + 2) & 3] = gwr[rec[(u + 2) & 3] & 0x7FFFu];
+            wb[(u + 2) & 3] = gwr[(rec[(u + 2) & 3] >> 16) & 0x7FFFu];
+            const uint32_t r0 = rec[u];
+            if (r0 >> 31) {
+                const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
+                double2 pa = lpos[ga], pb = lpos[gb];
+                project_pair<false>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
+                                    (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], wa[u], overlap, compliance, eps);
+                lpos[ga] = pa;
+                lpos[gb] = pb;
+            }
         }
-        const double2 wa2 = gwr[rec2 & 0x7FFFu], wb2 = gwr[(rec2 >> 16) & 0x7FFFu];
-        if (rec0 >> 31) {
-            const int ga = (int)(rec0 & 0x7FFFu), gb = (int)((rec0 >> 16) & 0x7FFFu);
-            double2 pa = lpos[ga], pb = lpos[gb];
-            project_pair<false>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
-                                (rec0 & 0x8000u) != 0, pa, pb, wa0, wb0, wa0, overlap, compliance, eps);
-            lpos[ga] = pa;
-            lpos[gb] = pb;
-        }
-        rec0 = rec1;
-        rec1 = rec2;
-        rec2 = rec3;
-        wa0 = wa1;
-        wb0 = wb1;
-        wa1 = wa2;
-        wb1 = wb2;
     }
     for (int i = lane; i < np; i += 64) gpos[i] = lpos[i];
 }

@@ -129,34 +129,37 @@ struct EggPackedArgs {
     const double *atom_tx, *atom_ty, *atom_fd;
     const int32_t *atom_claim;
     int32_t *atom_aabb_out, *atom_fail, *atom_disp_out;
-    const int32_t *tile_atom_begin;  // of this class's first tile; [n_tiles + 1]
-    const int32_t *tile_atoms;
+    const int32_t *tile_atoms;  // atom ids of all tiles of the type (tile_geo gives a tile's range)
     int32_t n_tiles, n_groups;
-    // packed layout of this class
-    const int32_t *tile_p0;    // [n_tiles + 1] packed index of each tile's first particle
-    const int32_t *grp_tile0;  // [n_groups + 1] first tile of each group
-    int32_t p_begin, p_end;    // packed range of the class
+    // Geometry of this class, computed by the host when tiles are formed, so that a kernel learns everything
+    // about its tile or group from ONE load (every dependent global load costs a full memory round trip):
+    const int32_t *tile_geo;    // [n_tiles][8]: first packed particle, particles, first entry in tile_atoms / tile_claims,
+                                //               atoms, cell origin x, y (claims' minimum - 2), grid width, height
+    const int32_t *tile_claims; // [4] per entry of tile_atoms: the atom's claim box {lo_x, lo_y, hi_x, hi_y}
+    const int32_t *grp_geo;     // [n_groups][4]: first tile, end tile, first packed particle, particles
+    int32_t p_begin, p_end;     // packed range of the class
     // packed per-particle arrays of the type (indexed by packed index)
     double *pk_pos, *pk_prev, *pk_wr;  // double2 each: position, position at the start of the sub-step, (inverse mass, radius)
     int32_t *pk_src;           // particle index in the particle-order arrays
     int32_t *pk_atom;          // atom id
+    uint16_t *pk_aslot;        // atom slot inside the tile
     uint32_t *pk_ckey;         // [2][pk_stride] packed cell of the last pass of each sub-step parity
     int32_t pk_stride;
     // per tile (class-relative), `scap` words each: the tile's pair STREAM in the reference's order -- the visit
     // entries self | slow << 15 | other << 16 (tile-local indices) of every particle as `self`, ascending
     uint32_t *lists;
     uint16_t *lvl;             // level of each stream entry
-    uint32_t *sorted;          // per group, from its first tile's slot: entries sorted by level, group-local indices
-    uint32_t *chunks;          // [n_groups][chunk_cap] the executor's work list: start | (count - 1) << 26 into `sorted`,
-                               // every chunk inside one level, levels ascending
+    // per group, `sort_cap` words each: the group's pairs sorted by level, every level padded to a multiple of 64
+    // entries (bit 31 marks a pair, padding is 0), indices group-local: the executor's chunk c is words [64 c, 64 c + 64)
+    uint32_t *sorted;
     int32_t *grp_nchunks;      // [n_groups]
     uint32_t *lev_start;       // [n_groups][lev_cap + 2] first slot of every level in the group's sorted list
     int32_t *grp_nlev;         // [n_groups]
-    int32_t *tile_total;       // [n_tiles] visit entries of the current pass
+    int32_t *tile_total;       // [n_tiles] visit entries of the current pass (0: the tile failed a check)
     int32_t *tile_visits;      // [EGG_PK_MAX_PASSES][n_tiles] n_collided of each pass (L:1657)
-    int32_t *tile_maxlist;     // [n_tiles] largest list of the step
+    int32_t *tile_need;        // [EGG_PK_MAX_PASSES][n_tiles] visit entries each pass needed (list capacity check)
     int32_t *tile_slack;       // [n_tiles]
-    int32_t lcap, scap, lev_cap, chunk_cap;
+    int32_t lcap, scap, lev_cap, sort_cap;
     // LDS geometry of egg_pk_lists
     int32_t nmax, amax, ccap, use_grid, stage_cap;
     // environment

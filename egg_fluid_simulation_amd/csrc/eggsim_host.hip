@@ -157,13 +157,13 @@ struct PackedClass {
     int p_begin = 0, p_end = 0;
     int tile_base = 0;      // first slot of the class in the per-tile arrays
     int group_base = 0;     // first slot in the per-group arrays
-    size_t meta_tile_p0 = 0, meta_grp_tile0 = 0;  // offsets (ints) into System::pk_meta
+    size_t meta_tile_geo = 0, meta_grp_geo = 0;  // offsets (ints) into System::pk_meta
     int max_group_particles = 0;
     int wd = 8;             // lanes per tile in the level walk
     int lcap = 0, scap = 0;  // visit entries / stream words (entries + one header per particle) a tile may have
     int stage_cap = 0;       // partners per particle the list kernel's counting pass keeps in LDS
-    int chunk_cap = 0;       // chunk descriptors per group
-    size_t chunk_base = 0;
+    int sort_cap = 0;        // words of a group's sorted list (every level padded to a multiple of 64)
+    size_t sort_base = 0;
     size_t entry_base = 0;  // first stream word of the class in the per-entry arrays
     size_t lds_lists = 0, lds_levels = 0, lds_exec = 0;
     int threads_lists = 64;
@@ -227,12 +227,13 @@ struct System {  // one particle type
     std::vector<int32_t> pk_meta_host;       // tile_p0 / grp_tile0 of every packed class
     DevBuf<int32_t> pk_meta, pk_src, pk_atom, pk_tile, pk_nchunks;
     DevBuf<double> pk_pos, pk_prev, pk_wr;
-    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_chunks, pk_levstart;
-    DevBuf<uint16_t> pk_lvl;
+    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_levstart;
+    DevBuf<uint16_t> pk_lvl, pk_aslot;
+    size_t pk_meta_claims = 0;               // offset (ints) of the tile claims inside pk_meta
     int pk_n = 0, pk_tiles = 0, pk_groups = 0;
     size_t pk_entries = 0;                   // stream words over all packed tiles
-    size_t pk_chunk_words = 0;               // chunk descriptors over all packed groups
-    int pk_lev_cap = 1023;                   // levels the tables hold; grows when a group's DAG is deeper
+    size_t pk_sort_words = 0;                // sorted-list words over all packed groups
+    int pk_lev_cap = 255;                    // levels the tables hold; grows when a group's DAG is deeper
     bool pk_plan_dirty = true;
     EggStatus *h_status = nullptr;  // the most recent launch's status block inside stage_down (pinned)
     hipStream_t stream = nullptr;
@@ -807,7 +808,7 @@ int retile(egg_handle *h, int which) {
     s.pk_meta_host.clear();
     s.pk_n = s.pk_tiles = s.pk_groups = 0;
     s.pk_entries = 0;
-    s.pk_chunk_words = 0;
+    s.pk_sort_words = 0;
     {
         // automatic: scenes large enough that the chip is full of tiles whatever the kernel (the fused kernel's
         // latency per step is lower while every tile has a CU almost to itself); judged on the white particles so
@@ -830,74 +831,98 @@ int retile(egg_handle *h, int which) {
             }
             pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap);
             if (pc.lds_lists > h->lds_limit) continue;
+            const size_t meta_mark = s.pk_meta_host.size();
             pc.p_begin = s.pk_n;
             pc.entry_base = s.pk_entries;
+            pc.sort_base = s.pk_sort_words;
             pc.tile_base = s.pk_tiles;
             pc.group_base = s.pk_groups;
-            pc.meta_tile_p0 = s.pk_meta_host.size();
+            // tile records: first packed particle, particles, first tile atom, atoms, cell origin, grid extent
+            pc.meta_tile_geo = (s.pk_meta_host.size() + 3) & ~(size_t)3;  // 16-byte aligned records
+            s.pk_meta_host.resize(pc.meta_tile_geo);
             int pn = s.pk_n;
+            std::vector<int> tile_first_particle((size_t)lc.n_tiles + 1);
             for (int t = 0; t < lc.n_tiles; ++t) {
-                s.pk_meta_host.push_back(pn);
-                pn += (int)tiles[(size_t)lc.first_tile + t].particles;
+                const size_t gt = (size_t)lc.first_tile + t;
+                const int a0 = s.tile_atom_begin[gt], a1 = s.tile_atom_begin[gt + 1];
+                int32_t lx = std::numeric_limits<int32_t>::max(), ly = lx, hx = std::numeric_limits<int32_t>::min(), hy = hx;
+                for (int k = a0; k < a1; ++k) {
+                    const Box &c = claim[(size_t)s.tile_atoms[(size_t)k]];
+                    lx = std::min(lx, c.lo_x);
+                    ly = std::min(ly, c.lo_y);
+                    hx = std::max(hx, c.hi_x);
+                    hy = std::max(hy, c.hi_y);
+                }
+                tile_first_particle[(size_t)t] = pn;
+                const int32_t rec[8] = {pn, (int32_t)tiles[gt].particles, a0, a1 - a0, lx - 2, ly - 2,
+                                        (int32_t)std::min<int64_t>((int64_t)hx - lx + 4, 65535), (int32_t)std::min<int64_t>((int64_t)hy - ly + 4, 65535)};
+                s.pk_meta_host.insert(s.pk_meta_host.end(), rec, rec + 8);
+                pn += (int)tiles[gt].particles;
             }
-            s.pk_meta_host.push_back(pn);
+            tile_first_particle[(size_t)lc.n_tiles] = pn;
             pc.p_end = pn;
             // groups: consecutive tiles while one wave's LDS holds their positions (tiles are sorted by size, largest first)
-            pc.meta_grp_tile0 = s.pk_meta_host.size();
+            pc.meta_grp_geo = s.pk_meta_host.size();
             const int64_t gp_max = std::max<int64_t>(h->opt_group_particles, tiles[(size_t)lc.first_tile].particles);
-            int64_t in_group = 0;
-            int tiles_in_group = 0;
-            for (int t = 0; t < lc.n_tiles; ++t) {
-                const int64_t np = tiles[(size_t)lc.first_tile + t].particles;
-                if (t == 0 || in_group + np > gp_max || in_group + np > 32767 || tiles_in_group >= 64) {
-                    s.pk_meta_host.push_back(t);
-                    pc.n_groups++;
-                    in_group = 0;
-                    tiles_in_group = 0;
-                }
-                in_group += np;
-                tiles_in_group++;
-                pc.max_group_particles = std::max<int>(pc.max_group_particles, (int)in_group);
-            }
-            s.pk_meta_host.push_back(lc.n_tiles);
-            const int per_group = (lc.n_tiles + pc.n_groups - 1) / pc.n_groups;
             int max_tiles_in_group = 0;
-            for (int gi = 0; gi < pc.n_groups; ++gi)
-                max_tiles_in_group = std::max(max_tiles_in_group, s.pk_meta_host[pc.meta_grp_tile0 + gi + 1] - s.pk_meta_host[pc.meta_grp_tile0 + gi]);
+            for (int t = 0; t < lc.n_tiles;) {
+                int64_t in_group = 0;
+                int t_end = t;
+                while (t_end < lc.n_tiles && t_end - t < 64) {
+                    const int64_t np = tiles[(size_t)lc.first_tile + t_end].particles;
+                    if (t_end > t && (in_group + np > gp_max || in_group + np > 32767)) break;
+                    in_group += np;
+                    ++t_end;
+                }
+                const int32_t rec[4] = {t, t_end, tile_first_particle[(size_t)t], (int32_t)in_group};
+                s.pk_meta_host.insert(s.pk_meta_host.end(), rec, rec + 4);
+                pc.n_groups++;
+                pc.max_group_particles = std::max<int>(pc.max_group_particles, (int)in_group);
+                max_tiles_in_group = std::max(max_tiles_in_group, t_end - t);
+                t = t_end;
+            }
+            const int per_group = (lc.n_tiles + pc.n_groups - 1) / pc.n_groups;
             pc.wd = per_group >= 8 ? 8 : 16;
             pc.lds_exec = (size_t)pc.max_group_particles * 16;
             pc.lds_levels = egg_pk_levels_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd);
-            const size_t group_words = (size_t)max_tiles_in_group * (size_t)pc.scap;
-            pc.chunk_cap = (int)std::min<size_t>(group_words / 64 + (size_t)s.pk_lev_cap + 4, (size_t)1 << 30);
-            if (pc.lds_exec > h->lds_limit || pc.lds_levels > h->lds_limit || group_words >= ((size_t)1 << 26)) {
-                s.pk_meta_host.resize(pc.meta_tile_p0);
+            const size_t sort_words = (size_t)max_tiles_in_group * (size_t)pc.scap + 64 * (size_t)s.pk_lev_cap + 64;
+            if (pc.lds_exec > h->lds_limit || pc.lds_levels > h->lds_limit || sort_words >= ((size_t)1 << 30)) {
+                s.pk_meta_host.resize(meta_mark);
                 continue;
             }
-            pc.chunk_base = s.pk_chunk_words;
+            pc.sort_cap = (int)sort_words;
             lc.packed = (int)s.pk.size();
             s.pk_n = pn;
             s.pk_tiles += lc.n_tiles;
             s.pk_groups += pc.n_groups;
             s.pk_entries += (size_t)lc.n_tiles * (size_t)pc.scap;
-            s.pk_chunk_words += (size_t)pc.n_groups * (size_t)pc.chunk_cap;
+            s.pk_sort_words += (size_t)pc.n_groups * (size_t)pc.sort_cap;
             s.pk.push_back(pc);
         }
         if (!s.pk.empty()) {
+            // the claims of every tile atom, in tile order (one load per atom slot in the kernels)
+            s.pk_meta_claims = (s.pk_meta_host.size() + 3) & ~(size_t)3;
+            s.pk_meta_host.resize(s.pk_meta_claims);
+            for (int32_t a : s.tile_atoms) {
+                const Box &c = claim[(size_t)a];
+                const int32_t rec[4] = {c.lo_x, c.lo_y, c.hi_x, c.hi_y};
+                s.pk_meta_host.insert(s.pk_meta_host.end(), rec, rec + 4);
+            }
             const size_t np = (size_t)s.pk_n, nt = (size_t)s.pk_tiles, ng = (size_t)s.pk_groups;
             HIP_TRY(h, s.pk_meta.reserve(s.pk_meta_host.size() + 4, false, s.stream));
             HIP_TRY(h, s.pk_src.reserve(np, false, s.stream));
             HIP_TRY(h, s.pk_atom.reserve(np, false, s.stream));
+            HIP_TRY(h, s.pk_aslot.reserve(np + 8, false, s.stream));
             HIP_TRY(h, s.pk_pos.reserve(2 * np, false, s.stream));
             HIP_TRY(h, s.pk_prev.reserve(2 * np, false, s.stream));
             HIP_TRY(h, s.pk_wr.reserve(2 * np, false, s.stream));
             HIP_TRY(h, s.pk_ckey.reserve(2 * np, false, s.stream));
             HIP_TRY(h, s.pk_lists.reserve(s.pk_entries + 64, false, s.stream));
-            HIP_TRY(h, s.pk_sorted.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_lvl.reserve(s.pk_entries + 64, false, s.stream));
-            HIP_TRY(h, s.pk_chunks.reserve(s.pk_chunk_words + 64, false, s.stream));
+            HIP_TRY(h, s.pk_sorted.reserve(s.pk_sort_words + 64, false, s.stream));
             HIP_TRY(h, s.pk_nchunks.reserve(2 * ng + 8, false, s.stream));
             HIP_TRY(h, s.pk_levstart.reserve(ng * ((size_t)s.pk_lev_cap + 2) + 64, false, s.stream));
-            HIP_TRY(h, s.pk_tile.reserve(nt * (3 + EGG_PK_MAX_PASSES) + 4, false, s.stream));
+            HIP_TRY(h, s.pk_tile.reserve(nt * (2 + 2 * EGG_PK_MAX_PASSES) + 4, false, s.stream));
         }
         s.pk_plan_dirty = true;
     }
@@ -1063,12 +1088,12 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.atom_aabb_out = d_aabb(s);
     A.atom_fail = s.d_atom_fail.p;
     A.atom_disp_out = d_disp(s);
-    A.tile_atom_begin = (const int32_t *)(s.d_meta.p + s.meta_off_tbegin) + lc.first_tile;
     A.tile_atoms = (const int32_t *)(s.d_meta.p + s.meta_off_tatoms);
     A.n_tiles = pc.n_tiles;
     A.n_groups = pc.n_groups;
-    A.tile_p0 = s.pk_meta.p + pc.meta_tile_p0;
-    A.grp_tile0 = s.pk_meta.p + pc.meta_grp_tile0;
+    A.tile_geo = s.pk_meta.p + pc.meta_tile_geo;
+    A.grp_geo = s.pk_meta.p + pc.meta_grp_geo;
+    A.tile_claims = s.pk_meta.p + s.pk_meta_claims;
     A.p_begin = pc.p_begin;
     A.p_end = pc.p_end;
     A.pk_pos = s.pk_pos.p;
@@ -1076,24 +1101,24 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.pk_wr = s.pk_wr.p;
     A.pk_src = s.pk_src.p;
     A.pk_atom = s.pk_atom.p;
+    A.pk_aslot = s.pk_aslot.p;
     A.pk_ckey = s.pk_ckey.p;
     A.pk_stride = s.pk_n;
     A.lists = s.pk_lists.p + pc.entry_base;
     A.lvl = s.pk_lvl.p + pc.entry_base;
-    A.sorted = s.pk_sorted.p + pc.entry_base;
-    A.chunks = s.pk_chunks.p + pc.chunk_base;
+    A.sorted = s.pk_sorted.p + pc.sort_base;
     A.grp_nchunks = s.pk_nchunks.p + pc.group_base;
     A.grp_nlev = s.pk_nchunks.p + s.pk_groups + pc.group_base;
     A.lev_start = s.pk_levstart.p + (size_t)pc.group_base * ((size_t)s.pk_lev_cap + 2);
-    int32_t *tb = s.pk_tile.p + (size_t)pc.tile_base * (3 + EGG_PK_MAX_PASSES);
+    int32_t *tb = s.pk_tile.p + (size_t)pc.tile_base * (2 + 2 * EGG_PK_MAX_PASSES);
     A.tile_total = tb;
-    A.tile_maxlist = tb + pc.n_tiles;
-    A.tile_slack = tb + 2 * (size_t)pc.n_tiles;
-    A.tile_visits = tb + 3 * (size_t)pc.n_tiles;
+    A.tile_slack = tb + pc.n_tiles;
+    A.tile_visits = tb + 2 * (size_t)pc.n_tiles;
+    A.tile_need = tb + (2 + (size_t)EGG_PK_MAX_PASSES) * (size_t)pc.n_tiles;
     A.lcap = pc.lcap;
     A.scap = pc.scap;
     A.lev_cap = s.pk_lev_cap;
-    A.chunk_cap = pc.chunk_cap;
+    A.sort_cap = pc.sort_cap;
     A.stage_cap = pc.stage_cap;
     A.nmax = lc.nmax;
     A.amax = lc.amax;
@@ -1184,6 +1209,9 @@ int launch_type(egg_handle *h, int which, const Env &env, int S, int C) {
     if (rc != EGG_OK) return rc;
     s.timing_from = which;
     if (h->opt_timing) HIP_TRY(h, hipEventRecord(s.ev0, s.stream));
+    // per-atom "left its claim" flags of the step: the packed pipeline's kernels only ever set them (tiles of the
+    // fused kernels reset their own atoms' flags themselves)
+    if (!s.pk.empty()) HIP_TRY(h, hipMemsetAsync(s.d_atom_fail.p, 0, s.atoms.size() * sizeof(int32_t), s.stream));
     for (const LaunchClass &lc : s.classes) {
         if (lc.packed >= 0) continue;  // stepped by the packed pipeline below
         EggStepArgs A;

@@ -38,11 +38,37 @@ namespace {
 // ------------------------------------------------------------------ visit lists with a visitor
 // (the same rules as enum_fresh / enum_stale in eggsim_tile.h; emit(position, other) is called in attempt order)
 
+// The packed path lays its dense cell grid out x-major (cell index = x * height + y): the three cells of one
+// column of the 3x3 loop (x offset outer, y inner, L:1568-1569) are then neighbours in memory, and -- the items being
+// sorted by cell -- their items form ONE contiguous run, already in the reference's order.
+__device__ inline uint32_t pk_cell_meta(const Tile &t, int gh, int buf, uint32_t key) {
+    if (t.use_grid) return t.cell(buf)[(int)(key >> 16) * gh + (int)(key & 0xFFFFu)];
+    return cell_meta(t, buf, key);
+}
+
 template <class F>
-__device__ inline int pk_visit_fresh(const Tile &t, int cur, int i, F emit) {
+__device__ inline int pk_visit_fresh(const Tile &t, int gh, int cur, int i, F emit) {
     const uint32_t ki = t.ckey(cur)[i];
     const uint16_t *items = t.hitems(cur);
     int count = 0;
+    if (t.use_grid) {
+        const uint32_t *cells = t.cell(cur);
+        const int h1 = (int)(ki >> 16) * gh + (int)(ki & 0xFFFFu);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int h0 = h1 + (p - 1) * gh - 1;  // cell (x + p - 1, y - 1); claimed cells have a ring of empty cells around
+            const uint32_t m0 = cells[h0], m2 = cells[h0 + 2];
+            const int st = (int)(m0 >> 16), en = (int)(m2 >> 16) + (int)(m2 & 0xFFFFu);
+            for (int e = st; e < en; ++e) {
+                const int j = items[e];
+                if (j > i) {
+                    emit(count, j);
+                    ++count;
+                }
+            }
+        }
+        return count;
+    }
     for (int p = 0; p < 3; ++p) {
         uint32_t m[3];
 #pragma unroll
@@ -63,14 +89,14 @@ __device__ inline int pk_visit_fresh(const Tile &t, int cur, int i, F emit) {
 }
 
 template <class F>
-__device__ inline int pk_visit_stale(const Tile &t, const PassCtx &c, int i, F emit) {
+__device__ inline int pk_visit_stale(const Tile &t, int gh, const PassCtx &c, int i, F emit) {
     const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.prev);
     const uint32_t kni = kn[i], koi = ko[i];
     const bool settled = c.prev_uncut && kni == koi;
     int count = 0;
     for (int s = 0; s < 9; ++s) {
         const uint32_t nk = (uint32_t)((int)kni + (s / 3 - 1) * 65536 + (s % 3 - 1));
-        const uint32_t mo = cell_meta(t, c.prev, nk), mn = cell_meta(t, c.cur, nk);
+        const uint32_t mo = pk_cell_meta(t, gh, c.prev, nk), mn = pk_cell_meta(t, gh, c.cur, nk);
 #pragma unroll
         for (int isnew = 0; isnew < 2; ++isnew) {
             const uint32_t m = isnew ? mn : mo;
@@ -91,7 +117,7 @@ __device__ inline int pk_visit_stale(const Tile &t, const PassCtx &c, int i, F e
 
 // Cell records (start << 16 | count) and per-cell item lists, ascending particle index inside a cell
 // (L:1509), of generation `buf`, from the packed cells in t.ckey(buf).  tmp: n words of scratch.
-__device__ inline void pk_build_grid(const Tile &t, int buf, uint32_t *tmp, int tid, int nthreads, uint32_t *wtot) {
+__device__ inline void pk_build_grid(const Tile &t, int gh, int buf, uint32_t *tmp, int tid, int nthreads, uint32_t *wtot) {
     const int n = t.n;
     for (int h = tid; h < t.ncell; h += nthreads) t.cell(buf)[h] = 0;
     if (!t.use_grid)
@@ -102,7 +128,7 @@ __device__ inline void pk_build_grid(const Tile &t, int buf, uint32_t *tmp, int 
         const uint32_t key = t.ckey(buf)[i];
         uint32_t h;
         if (t.use_grid) {
-            h = (key & 0xFFFFu) * (uint32_t)t.gw + (key >> 16);
+            h = (key >> 16) * (uint32_t)gh + (key & 0xFFFFu);  // x-major, see pk_cell_meta
             if (h >= (uint32_t)t.ncell) h = 0;  // only after a range / claim failure
         } else {
             h = hash_cell(key, t.ccap);
@@ -193,14 +219,15 @@ __device__ __forceinline__ int subwave_incl_max(int v, int sl) {
 extern "C" __global__ void __launch_bounds__(64) egg_pk_plan_kernel(EggPackedArgs A) {
     const int tile = blockIdx.x;
     if (tile >= A.n_tiles) return;
-    const int a0 = A.tile_atom_begin[tile], a1 = A.tile_atom_begin[tile + 1];
-    int p = A.tile_p0[tile];
-    for (int k = a0; k < a1; ++k) {
-        const int atom = A.tile_atoms[k];
+    const int4 geo = ((const int4 *)A.tile_geo)[2 * tile];
+    int p = geo.x;
+    for (int k = 0; k < geo.w; ++k) {
+        const int atom = A.tile_atoms[geo.z + k];
         const int g0 = A.atom_offset[atom], cnt = A.atom_count[atom];
         for (int q = threadIdx.x; q < cnt; q += 64) {
             A.pk_src[p + q] = g0 + q;
             A.pk_atom[p + q] = atom;
+            A.pk_aslot[p + q] = (uint16_t)k;
         }
         p += cnt;
     }
@@ -284,56 +311,37 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     }
     __shared__ uint32_t wtot[16];
 
-    const int a_begin = A.tile_atom_begin[tile];
-    const int na = A.tile_atom_begin[tile + 1] - a_begin;
+    // everything about the tile in one 32-byte record (a chain of dependent loads here -- tile -> atoms -> counts ->
+    // claims -- cost five memory round trips with the whole workgroup waiting)
+    const int4 geo0 = ((const int4 *)A.tile_geo)[2 * tile], geo1 = ((const int4 *)A.tile_geo)[2 * tile + 1];
+    const int p0 = __builtin_amdgcn_readfirstlane(geo0.x), n = __builtin_amdgcn_readfirstlane(min(geo0.y, A.nmax));
+    const int a_begin = __builtin_amdgcn_readfirstlane(geo0.z), na = __builtin_amdgcn_readfirstlane(min(geo0.w, A.amax));
+    const int org_x = __builtin_amdgcn_readfirstlane(geo1.x), org_y = __builtin_amdgcn_readfirstlane(geo1.y);
     t.na = na;
-    const int p0 = A.tile_p0[tile];
-    if (tid == 0) {
-        int off = 0;
-        int ox = 0x7FFFFFFF, oy = 0x7FFFFFFF, hx = -0x7FFFFFFF, hy = -0x7FFFFFFF;
-        for (int k = 0; k < na; ++k) {
-            const int atom = A.tile_atoms[a_begin + k];
-            if (A.pass_seq == 0) A.atom_fail[atom] = 0;
-            t.aoff[k] = off;
-            off += A.atom_count[atom];
-            for (int q = 0; q < 4; ++q) t.aclaim[4 * k + q] = A.atom_claim[4 * atom + q];
-            ox = min(ox, t.aclaim[4 * k + 0]);
-            oy = min(oy, t.aclaim[4 * k + 1]);
-            hx = max(hx, t.aclaim[4 * k + 2]);
-            hy = max(hy, t.aclaim[4 * k + 3]);
-        }
-        t.aoff[na] = off;
-        t.sc[2] = off;
-        t.sc[3] = ox - 2;  // packed cells are relative to (ox - 2, oy - 2), see egg_step_body
-        t.sc[4] = oy - 2;
-        const long long gw = (long long)hx - ox + 4, gh = (long long)hy - oy + 4;
-        t.sc[6] = (int)min(gw, 65535ll);
-        t.sc[7] = (int)min(gh, 65535ll);
-        if (gw > 65534ll || gh > 65534ll) atomicExch(&A.status->fail_range, 1);
-        if (A.use_grid && gw * gh > (long long)A.ccap) atomicExch(&A.status->fail_overflow, 1);
-        if (off > A.nmax || na > A.amax) atomicExch(&A.status->fail_overflow, 1);
-    }
-    __syncthreads();
-    const int n = __builtin_amdgcn_readfirstlane(min(t.sc[2], A.nmax));
     t.n = n;
-    const int org_x = __builtin_amdgcn_readfirstlane(t.sc[3]), org_y = __builtin_amdgcn_readfirstlane(t.sc[4]);
-    t.gw = __builtin_amdgcn_readfirstlane(t.sc[6]);
-    t.ncell = A.use_grid ? __builtin_amdgcn_readfirstlane((int)min((long long)t.sc[6] * t.sc[7], (long long)A.ccap)) : A.ccap;
-
-    for (int k = 0; k < na; ++k) {
-        const int l0 = t.aoff[k], cnt = t.aoff[k + 1] - l0;
-        for (int q = tid; q < cnt; q += nthreads)
-            if (l0 + q < n) t.aslot[l0 + q] = (uint16_t)k;
-    }
+    t.gw = __builtin_amdgcn_readfirstlane(geo1.z);
+    const int gh = __builtin_amdgcn_readfirstlane(geo1.w);
+    t.ncell = A.use_grid ? __builtin_amdgcn_readfirstlane((int)min((long long)geo1.z * geo1.w, (long long)A.ccap)) : A.ccap;
+    for (int k = tid; k < na; k += nthreads) ((int4 *)t.aclaim)[k] = ((const int4 *)A.tile_claims)[a_begin + k];
     const int cur = 0, prev = 1;  // LDS generation buffers of this launch
     uint32_t *g_ckey_cur = A.pk_ckey + (size_t)(A.substep & 1) * A.pk_stride + p0;
     const uint32_t *g_ckey_prev = A.pk_ckey + (size_t)((A.substep + 1) & 1) * A.pk_stride + p0;
     for (int i = tid; i < n; i += nthreads) {
         t.pos[i] = ((const double2 *)A.pk_pos)[p0 + i];
         t.wr[i] = ((const double2 *)A.pk_wr)[p0 + i];
+        t.aslot[i] = A.pk_aslot[p0 + i];
         if (STALE) t.ckey(prev)[i] = g_ckey_prev[i];
     }
-    __syncthreads();
+    // Can every pair of this tile take the hand-expanded arithmetic (pair_needs_reference false for all of them)?
+    // Sufficient per particle: eps / 2 <= w <= 2^298 and |overlap * r| <= 2^298, with the compliance <= 2^298: then
+    // eps <= w_i + w_j, eps <= divisor <= 2^300 and min_distance^2 <= 2^600 for every pair (floating-point addition is
+    // monotonic; NaN fails the comparisons).  Nearly always true; the per-pair test then drops out of the fill.
+    bool mine_fast = A.collision_compliance <= 0x1p298;
+    for (int i = tid; i < n; i += nthreads) {
+        const double2 w = t.wr[i];
+        mine_fast = mine_fast && (w.x >= A.eps * 0.5) && (w.x <= 0x1p298) && (fabs(A.overlap_factor * w.y) <= 0x1p298);
+    }
+    const bool all_fast = __syncthreads_and(mine_fast) != 0;
 
     // ----------------------------------- spatial hash of this pass, L:1486-1511 (claim check as in egg_step_body)
     bool bad = false;
@@ -358,8 +366,8 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     int total = 0;
     uint32_t guarded = 0;
     if (!any_bad) {
-        pk_build_grid(t, cur, tmp, tid, nthreads, wtot);
-        if (STALE) pk_build_grid(t, prev, tmp, tid, nthreads, wtot);
+        pk_build_grid(t, gh, cur, tmp, tid, nthreads, wtot);
+        if (STALE) pk_build_grid(t, gh, prev, tmp, tid, nthreads, wtot);
         PassCtx ctx;
         ctx.cur = cur;
         ctx.prev = prev;
@@ -376,7 +384,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
             auto keep = [&](int k, int j) {
                 if (k < SC) slots[k] = (uint16_t)j;
             };
-            t.fill[i] = STALE ? (uint32_t)pk_visit_stale(t, ctx, i, keep) : (uint32_t)pk_visit_fresh(t, cur, i, keep);
+            t.fill[i] = STALE ? (uint32_t)pk_visit_stale(t, gh, ctx, i, keep) : (uint32_t)pk_visit_fresh(t, gh, cur, i, keep);
         }
         __syncthreads();
         block_exclusive_scan<false>(t.fill, own_off, n, tid, nthreads, wtot);
@@ -387,8 +395,8 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     if (tid == 0) {
         if (any_bad) atomicExch(&A.status->fail_claim, 1);
         if (!fits) atomicExch(&A.status->fail_overflow, 1);
-        const int before = A.pass_seq == 0 ? 0 : A.tile_maxlist[tile];
-        A.tile_maxlist[tile] = max(before, total);  // what the pass needs, even when it does not fit
+        const size_t slot = (size_t)min(A.pass_seq, EGG_PK_MAX_PASSES - 1) * A.n_tiles + tile;
+        A.tile_need[slot] = total;  // what the pass needs, even when it does not fit
         // a tile that failed a check gets an empty stream: the later phases then leave it alone (the step is re-run)
         A.tile_total[tile] = (fits && !any_bad) ? total : 0;
     }
@@ -407,7 +415,10 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
                 if (slow && wi.x + wj.x < A.eps) ++guarded;
                 dst[k] = (uint32_t)i | (slow ? 0x8000u : 0u) | ((uint32_t)j << 16);
             };
-            if (cnt <= SC) {
+            if (cnt <= SC && all_fast) {
+                const uint16_t *slots = stage + (size_t)i * SC;
+                for (int k = 0; k < cnt; ++k) dst[k] = (uint32_t)i | ((uint32_t)slots[k] << 16);
+            } else if (cnt <= SC) {
                 const uint16_t *slots = stage + (size_t)i * SC;
                 for (int k = 0; k < cnt; ++k) emit(k, (int)slots[k]);
             } else if (STALE) {
@@ -419,9 +430,9 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
                 ctx.stale = 1;
                 ctx.prev_uncut = 1;
                 ctx.cut_mask = 0;
-                pk_visit_stale(t, ctx, i, emit);
+                pk_visit_stale(t, gh, ctx, i, emit);
             } else {
-                pk_visit_fresh(t, cur, i, emit);
+                pk_visit_fresh(t, gh, cur, i, emit);
             }
         }
     }
@@ -455,11 +466,12 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
     const int lane = threadIdx.x;
-    const int t0 = A.grp_tile0[g], t1 = A.grp_tile0[g + 1];
-    const int p0 = A.tile_p0[t0], np = A.tile_p0[t1] - p0;
+    const int4 gg = ((const int4 *)A.grp_geo)[g];
+    const int t0 = __builtin_amdgcn_readfirstlane(gg.x), t1 = __builtin_amdgcn_readfirstlane(gg.y);
+    const int p0 = __builtin_amdgcn_readfirstlane(gg.z), np = __builtin_amdgcn_readfirstlane(gg.w);
     const int lev_cap = A.lev_cap;
     constexpr int NSUB = 64 / WD, W = EGG_PK_WINDOW;
-    uint32_t *hist = (uint32_t *)smem;  // [lev_cap + 2] pairs per level, later the running fill offsets
+    uint32_t *hist = (uint32_t *)smem;  // [lev_cap + 2] pairs per level
     uint16_t *last = (uint16_t *)(smem + egg_align16((size_t)(lev_cap + 2) * 4));  // [np] level of each particle's last pair
     uint32_t *win_all = (uint32_t *)(smem + egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)np * 2));
     for (int i = lane; i <= lev_cap + 1; i += 64) hist[i] = 0;
@@ -470,10 +482,10 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
     int maxlev = 0;
     bool over = false;
     for (int ti = t0 + sub; ti < t1; ti += NSUB) {
-        const int tp0 = A.tile_p0[ti], base = tp0 - p0;
+        const int base = ((const int4 *)A.tile_geo)[2 * ti].x - p0;
+        const int slen = A.tile_total[ti];
         const uint32_t *stream = A.lists + (size_t)ti * A.scap;
         uint16_t *lv = A.lvl + (size_t)ti * A.scap;
-        const int slen = A.tile_total[ti];
         // One turn = the next (at most WD) entries of ONE self: the entries of a self are contiguous and carry it, so
         // the run's length inside the window is found with a ballot; last[self] is re-read from LDS every turn, which
         // also chains the pieces of a run longer than WD.  No branch depends on the run structure.
@@ -543,29 +555,21 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
         atomicMax(&A.status->max_level, maxlev);
     }
     const int nlev = min(maxlev, lev_cap);
-    // start of every level inside the group's sorted list (exclusive scan of the histogram; level 0 is empty), and
-    // the executor's work list: chunks of at most 64 pairs, each inside one level, levels ascending
-    uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
+    // first slot of every level in the group's sorted list; every level is padded to whole chunks of 64 (level 0 is empty)
     uint32_t *lstart = A.lev_start + (size_t)g * (lev_cap + 2);
-    uint32_t carry = 0, ccarry = 0;
+    uint32_t carry = 0;
     for (int b0 = 1; b0 <= nlev; b0 += 64) {
         const int L = b0 + lane;
-        const uint32_t v = (L <= nlev) ? hist[L] : 0u;
-        const uint32_t nch = (v + 63u) >> 6;
-        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane), cincl = (uint32_t)wave_incl_scan((int)nch, lane);
-        const uint32_t start = carry + incl - v, cb = ccarry + cincl - nch;
-        if (L <= nlev) {
-            lstart[L] = start;
-            for (uint32_t c = 0; c < nch; ++c)
-                if (cb + c < (uint32_t)A.chunk_cap) chunks[cb + c] = (start + 64u * c) | ((min(64u, v - 64u * c) - 1u) << 26);
-        }
+        const uint32_t v = (L <= nlev) ? ((hist[L] + 63u) & ~63u) : 0u;
+        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane);
+        if (L <= nlev) lstart[L] = carry + incl - v;
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        ccarry += (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
     }
     // an overflowed group is left alone by the later phases (the step is re-run with larger tables)
-    const bool usable = !over && ccarry <= (uint32_t)A.chunk_cap;
+    const bool usable = !over && carry <= (uint32_t)A.sort_cap;
     if (lane == 0) {
-        A.grp_nchunks[g] = usable ? (int)ccarry : 0;
+        lstart[nlev + 1] = carry;
+        A.grp_nchunks[g] = usable ? (int)(carry >> 6) : 0;
         A.grp_nlev[g] = usable ? nlev : 0;
     }
 }
@@ -574,49 +578,60 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_levels16_kernel(EggPacke
 extern "C" __global__ void __launch_bounds__(64) egg_pk_levels64_kernel(EggPackedArgs A) { egg_pk_levels_body<64>(A); }
 
 // Phase 2b: counting sort of a group's pairs by level (one workgroup per group: the walk above is one wave, this
-// part has no dependencies and wants many loads in flight).  Indices become group-local; bit 31 marks a pair.
+// part has no dependencies and wants many loads in flight).  Indices become group-local; bit 31 marks a pair; the
+// padding behind every level is zeroed.
 extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_kernel(EggPackedArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *cursor = (uint32_t *)smem;  // [nlev + 1] next free slot of every level
+    uint32_t *cursor = (uint32_t *)smem;  // [nlev + 2] next free slot of every level
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
     const int tid = threadIdx.x;
     const int nlev = A.grp_nlev[g];
     if (nlev <= 0) return;
-    const int t0 = A.grp_tile0[g], t1 = A.grp_tile0[g + 1];
-    const int p0 = A.tile_p0[t0];
+    const int4 gg = ((const int4 *)A.grp_geo)[g];
+    const int t0 = gg.x, t1 = gg.y, p0 = gg.z;
     const uint32_t *lstart = A.lev_start + (size_t)g * (A.lev_cap + 2);
-    for (int L = 1 + tid; L <= nlev; L += 256) cursor[L] = lstart[L];
+    for (int L = 1 + tid; L <= nlev + 1; L += 256) cursor[L] = lstart[L];
     __syncthreads();
-    uint32_t *sorted = A.sorted + (size_t)t0 * A.scap;
-    for (int ti = t0; ti < t1; ++ti) {
-        const uint32_t base = (uint32_t)(A.tile_p0[ti] - p0);
+    uint32_t *sorted = A.sorted + (size_t)g * A.sort_cap;
+    // a wave per tile, twelve entries per lane requested before the first is used: a sparse tile's whole stream in one
+    // memory round trip
+    const int lane = tid & 63;
+    for (int ti = t0 + (tid >> 6); ti < t1; ti += 4) {
+        const uint32_t base = (uint32_t)(((const int4 *)A.tile_geo)[2 * ti].x - p0);
         const uint32_t *stream = A.lists + (size_t)ti * A.scap;
         const uint16_t *lv = A.lvl + (size_t)ti * A.scap;
         const int slen = A.tile_total[ti];
-        for (int e0 = 0; e0 < slen; e0 += 1024) {
-            uint32_t rec[4], l[4];
+        for (int e0 = 0; e0 < slen; e0 += 768) {
+            uint32_t rec[12], l[12];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + 256 * u + tid, slen - 1);
+            for (int u = 0; u < 12; ++u) {
+                const int e = min(e0 + 64 * u + lane, slen - 1);
                 rec[u] = stream[e];
                 l[u] = (uint32_t)lv[e];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (e0 + 256 * u + tid < slen) {
+            for (int u = 0; u < 12; ++u)
+                if (e0 + 64 * u + lane < slen) {
                     const uint32_t pos = atomicAdd(&cursor[l[u]], 1u);
                     sorted[pos] = 0x80000000u | ((rec[u] & 0x7FFFu) + base) | (rec[u] & 0x8000u) | ((((rec[u] >> 16) & 0x7FFFu) + base) << 16);
                 }
         }
     }
+    __syncthreads();
+    // padding: from where a level's pairs end to where the next level starts (fewer than 64 words)
+    for (int L = 1 + tid; L <= nlev; L += 256) {
+        const uint32_t end = lstart[L + 1];
+        for (uint32_t x = cursor[L]; x < end; ++x) sorted[x] = 0u;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 3: the pair projections (L:1514-1545, L:1632-1654), chunk after chunk: at most 64 pairs of one level per
-// wave-instruction.  The work list is static, so the loads of the next chunks run ahead of the arithmetic: the
-// entries two chunks ahead, the (inverse mass, radius) records of both particles one chunk ahead; only the
-// positions are read when they are needed -- from LDS.
+// Phase 3: the pair projections (L:1514-1545, L:1632-1654), chunk after chunk: the 64 words [64 c, 64 c + 64) of
+// the group's sorted list are pairs of ONE level (or padding), so a wave-instruction projects up to 64 pairs.  The
+// work list is static, so the loads of the next chunks run ahead of the arithmetic: the entries three chunks
+// ahead, the (inverse mass, radius) records of both particles two chunks ahead; only the positions are read when
+// they are needed -- from LDS.
 extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *lpos = (double2 *)smem;
@@ -625,10 +640,17 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
     const int lane = threadIdx.x;
     const int nch = A.grp_nchunks[g];
     if (nch <= 0) return;  // nothing to do: positions stay as they are
-    const int t0 = A.grp_tile0[g], t1 = A.grp_tile0[g + 1];
-    const int p0 = A.tile_p0[t0], np = A.tile_p0[t1] - p0;
+    const int4 gg = ((const int4 *)A.grp_geo)[g];
+    const int p0 = __builtin_amdgcn_readfirstlane(gg.z), np = __builtin_amdgcn_readfirstlane(gg.w);
     double2 *gpos = (double2 *)A.pk_pos + p0;
     const double2 *gwr = (const double2 *)A.pk_wr + p0;
+    const uint32_t *sorted = A.sorted + (size_t)g * A.sort_cap + lane;
+    // Software pipeline over the static work list.  The ring of four stages is indexed with compile-time constants
+    // (the loop is unrolled by four), so nothing is copied and no load is waited for before its chunk is due.
+    uint32_t rec[4];
+    double2 wa[4], wb[4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) rec[u] = (u < nch) ? sorted[64 * u] : 0u;
     // the group's positions into LDS: eight loads in flight per lane (a load-wait-store loop pays one memory
     // round trip per 64 particles)
     for (int i0 = 0; i0 < np; i0 += 512) {
@@ -640,26 +662,7 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
 #pragma unroll
         for (int u = 0; u < 8; ++u) lpos[min(i0 + 64 * u + lane, np - 1)] = v[u];
     }
-    const uint32_t *sorted = A.sorted + (size_t)t0 * A.scap;
-    const uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
     const double overlap = A.overlap_factor, compliance = A.collision_compliance, eps = A.eps;
-    // chunk descriptors: 64 at a time in a register, picked out with readlane
-    uint32_t dreg = (lane < nch) ? chunks[lane] : 0u;
-    auto load_rec = [&](int c) -> uint32_t {  // the entries of chunk c (0 beyond the work list); bit 31 set on real entries
-        if (c >= nch) return 0u;
-        if ((c & 63) == 0 && c > 0) dreg = (c + lane < nch) ? chunks[c + lane] : 0u;  // next block of descriptors
-        const uint32_t desc = (uint32_t)__builtin_amdgcn_readlane((int)dreg, c & 63);
-        const uint32_t start = desc & 0x3FFFFFFu, cnt = (desc >> 26) + 1u;
-        return ((uint32_t)lane < cnt) ? sorted[start + (uint32_t)lane] : 0u;
-    };
-    // Software pipeline over the static work list: the entries of a chunk are requested three chunks ahead, the
-    // (inverse mass, radius) records of its particles two chunks ahead.  The ring of four stages is indexed with
-    // compile-time constants (the loop is unrolled by four), so nothing is copied and no load is waited for
-    // before its chunk is due.
-    uint32_t rec[4];
-    double2 wa[4], wb[4];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) rec[u] = load_rec(u);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         wa[u] = gwr[rec[u] & 0x7FFFu];
@@ -669,11 +672,11 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u;
-            rec[(u + 3) & 3] = load_rec(c + 3);
+            rec[(u + 3) & 3] = sorted[64 * min(c + 3, nch - 1)];  // (past the end: the last chunk again, never used)
             wa[(u + 2) & 3] = gwr[rec[(u + 2) & 3] & 0x7FFFu];
             wb[(u + 2) & 3] = gwr[(rec[(u + 2) & 3] >> 16) & 0x7FFFu];
             const uint32_t r0 = rec[u];
-            if (r0 >> 31) {
+            if (c < nch && (r0 >> 31)) {
                 const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
                 double2 pa = lpos[ga], pb = lpos[gb];
                 project_pair<false>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
@@ -693,20 +696,20 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_end_kernel(EggPackedArg
     const int tile = blockIdx.x;
     if (tile >= A.n_tiles) return;
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int a_begin = A.tile_atom_begin[tile], na = A.tile_atom_begin[tile + 1] - a_begin;
+    const int4 geo = ((const int4 *)A.tile_geo)[2 * tile];
+    const int a_begin = geo.z, na = geo.w;
     __shared__ int32_t red[8];
     __shared__ int32_t wslack[4];
     int slack = 0x7FFFFFFF;
-    int p = A.tile_p0[tile];
+    int p = geo.x;
     for (int k = 0; k < na; ++k) {
         const int atom = A.tile_atoms[a_begin + k];
         const int cnt = A.atom_count[atom];
         __syncthreads();
         if (tid < 8) red[tid] = (tid < 2) ? 0x7FFFFFFF : (tid < 4) ? -0x7FFFFFFF : 0;
         __syncthreads();
-        int32_t cl[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cl[q] = A.atom_claim[4 * atom + q];
+        const int4 clv = ((const int4 *)A.tile_claims)[a_begin + k];
+        const int32_t cl[4] = {clv.x, clv.y, clv.z, clv.w};
         int lo_x = 0x7FFFFFFF, lo_y = 0x7FFFFFFF, hi_x = -0x7FFFFFFF, hi_y = -0x7FFFFFFF;
         int d0 = 0, d1 = 0, d2 = 0, d3 = 0;
         for (int q = tid; q < cnt; q += nthreads) {
@@ -798,10 +801,8 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_reduce_kernel(EggPacke
         return;
     }
     int slack = 0x7FFFFFFF, ml = 0;
-    for (int t = tid; t < A.n_tiles; t += 1024) {
-        slack = min(slack, A.tile_slack[t]);
-        ml = max(ml, A.tile_maxlist[t]);
-    }
+    for (int t = tid; t < A.n_tiles; t += 1024) slack = min(slack, A.tile_slack[t]);
+    for (size_t x = tid; x < (size_t)n_passes * A.n_tiles; x += 1024) ml = max(ml, A.tile_need[x]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         slack = min(slack, __shfl_xor(slack, d, 64));

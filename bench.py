@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the XPBD particle step on MI355X (driver contract: one JSON line on rank 0).
 
-    python bench.py                       # 1 GPU, BASELINE config 2 (256 non-overlapping batches)
-    python bench.py --batches 4096        # other batch counts (not the headline config)
+    python bench.py                         # 1 GPU, BASELINE config 3: 4096 batches, 4 coincident per site
+    python bench.py --batches 256 --overlap 1      # BASELINE config 2 (the latency case; also reported by default)
+    python bench.py --batches 16384 --overlap 1    # one GPU's share of BASELINE config 4 / the whole of it on one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one SimulationHandler:_step (dt = 1/60, 2 sub-steps x 3 collision passes,
 simulation_handler.lua:1722) over every particle of the workload.  Inputs are resident in HBM
 before the timed region (the handler owns the particle arrays on the device).
+
+Workload at N = 1: the largest single-GPU configuration of BASELINE.json -- config 3 (4096 batches, every
+four consecutive batches on one centre: 704,512 particles in 1024 dense islands).  Config 2 (256 separate
+batches, one island per CU: a latency test) is timed in the same run and reported as `latency_config2`.
 
 Multi-GPU: the plane is cut into N x-slabs of `--batches` batches each (weak scaling); every
 rank steps its slab with its own handler and the ranks exchange the cell boxes of their
@@ -18,7 +23,15 @@ cross-rank data the path needs while no batch crosses a cut.
 value = pair solves (visited pairs, simulation_handler.lua:1657) per second over ALL ranks;
 steps_per_sec is the lock-step rate of the whole job.  The reference Lua path cannot be timed
 (no Lua interpreter in this pipeline); cpu_baseline times the sequential C restatement
-(oracle/, single thread because the reference is single-threaded) on the same workload.
+(oracle/, single thread because the reference is single-threaded) on sites of the same workload.
+
+roofline: SURVEY.md 8d's byte model prices a step at 592 B per particle.  Large scenes run the PACKED pipeline
+(one launch per phase, csrc/eggsim_packed.hip): `kernel_ms` is then the sum of the average HIP-event durations of
+all launches that step the white particles (the yolk launches run beside them on their own stream), measured in
+a short profiling leg after the timed region; `dominant_kernel` names the launch kind with the largest share.
+Small scenes run the fused step kernel: one launch per step, timed inside the timed region.  `traffic` and
+`valu` are rocprofv3 counter measurements of the same workload committed under profiles/ (they cannot be taken
+from inside the process); they are attached only when the workload matches.
 """
 import argparse
 import json
@@ -36,6 +49,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_PARTICLE_STEP = 592.0  # SURVEY.md 8d / BASELINE.md: FP64 SoA, state round-trips HBM once per phase
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 PITCH = 160.0                         # px between batch centres (BASELINE config 2: islands never touch)
+COUNTER_FILE = os.path.join(ROOT, "profiles", "r02_counters.json")  # written by scripts/collect_counters.py
 
 
 def site_pitch(overlap=1):
@@ -55,10 +69,21 @@ def grid_positions(n_batches, column_offset=0, overlap=1):
     return xs.astype(np.float64), ys.astype(np.float64), side
 
 
-def cpu_baseline(n_batches, budget_s=12.0):
-    """The CPU oracle on the same workload, single thread, bounded to ~budget_s seconds."""
+def workload_name(batches, overlap):
+    if overlap == 1:
+        tag = {256: "BASELINE config 2", 16384: "BASELINE config 4 on one GPU", 65536: "BASELINE config 5 on one GPU"}.get(batches)
+        return "%s%d non-overlapping batches per GPU" % (tag + ": " if tag else "", batches)
+    tag = "BASELINE config 3: " if (batches, overlap) == (4096, 4) else "BASELINE config 3 layout: "
+    return "%s%d batches per GPU, %d coincident per site" % (tag, batches, overlap)
+
+
+def cpu_baseline(n_batches, overlap, budget_s=12.0):
+    """The CPU oracle on sites of the same workload, single thread, bounded to ~budget_s seconds.  Sites are
+    independent islands, so the oracle steps a SAMPLE of them (its cost per step grows with the island count);
+    pair-solves/s is a rate and needs no extrapolation."""
     from oracle.oracle import Oracle
-    xs, ys, _ = grid_positions(n_batches)
+    sample = min(n_batches, 64 if overlap == 1 else 8 * overlap)
+    xs, ys, _ = grid_positions(sample, overlap=overlap)
     o = Oracle()
     for x, y in zip(xs, ys):
         o.add(float(x), float(y), 50, 15)
@@ -76,24 +101,66 @@ def cpu_baseline(n_batches, budget_s=12.0):
             break
     pairs = o.total_visited - v0
     return {"value": pairs / dt, "unit": "pair-solves/s", "cores": 1, "kind": "port",
-            "steps_per_sec": steps / dt,
+            "batch_steps_per_sec": sample * steps / dt,
             "sample": "oracle/eggsim_oracle.c (sequential C restatement of the Lua step; the Lua reference itself "
-                      "cannot run here), same %d-batch workload, %d timed steps after %d warm-up, 1 thread of %d host "
-                      "cores" % (n_batches, steps, warm, os.cpu_count() or 0)}
+                      "cannot run here): %d batches of the same layout (%d per site), %d timed steps after %d warm-up, "
+                      "1 thread of %d host cores; islands are independent, the whole workload costs the CPU "
+                      "%.0f x this sample per step" % (sample, overlap, steps, warm, os.cpu_count() or 0, n_batches / sample)}
+
+
+def timed_run(h, one_step, steps, warmup, torch, dist, timing_option):
+    from egg_fluid_simulation_amd import _ffi
+    for _ in range(warmup):
+        one_step()
+    h.set_option(_ffi.OPT_TIMING, timing_option)  # HIP events around the step launches, on the streams they run on
+    h.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    s0 = h.stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    h.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0, s0, h.stats()
+
+
+def latency_config2(torch, device, steps=200, warmup=30):
+    """BASELINE config 2 (256 separate batches, one island per CU): the step latency of the fused kernel"""
+    from egg_fluid_simulation_amd import WHITE, SimulationHandler
+    h = SimulationHandler(device=device)
+    xs, ys, _ = grid_positions(256)
+    h.add_many(xs, ys, 50, 15)
+    elapsed, s0, s1 = timed_run(h, lambda: h.step(1 / 60, 2, 3), steps, warmup, torch, None, 1)
+    n_w, n_y = h.get_n_particles()
+    kernel_ms = s1["kernel_ms_sum"][WHITE] / max(1, s1["timed_steps"])
+    out = {"workload": workload_name(256, 1), "particles": n_w + n_y, "steps": steps,
+           "ms_per_step": 1e3 * elapsed / steps, "steps_per_sec": steps / elapsed,
+           "pair_solves_per_sec": (s1["pair_solves"] - s0["pair_solves"]) / elapsed,
+           "kernel": "egg_step_kernel_multi_wide (one launch per step, white + yolk tiles)" if s1["fused_launch"] else "egg_step_kernel*",
+           "kernel_ms": kernel_ms,
+           "roofline_frac": ALGO_BYTES_PER_PARTICLE_STEP * (n_w + n_y) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else None}
+    del h
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batches", type=int, default=256, help="batches per GPU (256 = BASELINE config 2)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batches", type=int, default=4096, help="batches per GPU (4096 with --overlap 4 = BASELINE config 3)")
+    ap.add_argument("--overlap", type=int, default=4, help="coincident batches per site (4 = BASELINE config 3, 1 = separate batches)")
     ap.add_argument("--tile-target", type=int, default=0, help="pack independent islands into tiles of this size")
-    ap.add_argument("--overlap", type=int, default=1, help="coincident batches per site (4 = BASELINE config 3; not the headline config)")
     ap.add_argument("--no-fuse", action="store_true", help="one launch per particle type even on a full chip (A/B testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the config-2 latency block")
     ap.add_argument("--packed", type=int, default=-1, help="packed pipeline: -1 automatic, 0 never, 1 always (A/B testing)")
     ap.add_argument("--group-particles", type=int, default=0, help="packed pipeline: particles per executor wave (0 = default)")
+    ap.add_argument("--profile-steps", type=int, default=20, help="steps of the per-kernel timing leg after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,7 +196,7 @@ def main():
     if args.group_particles:
         h.set_option(_ffi.OPT_GROUP_PARTICLES, args.group_particles)
     xs, ys, side = grid_positions(args.batches, column_offset=rank, overlap=args.overlap)
-    ids = h.add_many(xs, ys, 50, 15)
+    h.add_many(xs, ys, 50, 15)
     n_white, n_yolk = h.get_n_particles()
     pitch = site_pitch(args.overlap)
     halo = BoundaryExchange(h, rank, world, slab_lo=100.0 + pitch * rank * side - pitch / 2,
@@ -147,23 +214,7 @@ def main():
         halo.finish()
         h.step_end(True)
 
-    for _ in range(args.warmup):
-        one_step()
-    h.set_option(_ffi.OPT_TIMING, 1)  # HIP events around the step launches, on the streams they run on
-    h.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    s0 = h.stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    h.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    s1 = h.stats()
+    elapsed, s0, s1 = timed_run(h, one_step, args.steps, args.warmup, torch, dist, 1)
 
     pairs = float(s1["pair_solves"] - s0["pair_solves"])
     follows = float(s1["follow_solves"] - s0["follow_solves"])
@@ -180,21 +231,53 @@ def main():
     else:
         total_particles = float(n_white + n_yolk)
 
+    # per-kernel leg (outside the timed region): HIP events around every launch of the packed pipeline
+    per_kernel = None
+    if rank == 0 and s1["packed"][WHITE] and args.profile_steps > 0:
+        h.set_option(_ffi.OPT_TIMING, 2)
+        for _ in range(args.profile_steps):
+            one_step() if halo is None else h.step(1 / 60, 2, 3)
+        h.synchronize()
+        sp = h.stats()
+        per_kernel = []
+        for w, tag in ((WHITE, "white"), (YOLK, "yolk")):
+            for k, name in enumerate(_ffi.PK_KINDS):
+                n = sp["pk_kernel_launches"][w][k]
+                if n:
+                    groups = n / max(1, sp["packed"][w])  # launches of one kind: one per class of the type
+                    per_kernel.append({"kernel": name, "type": tag, "avg_ms": sp["pk_kernel_ms"][w][k] / groups,
+                                       "launches_per_step": groups / args.profile_steps,
+                                       "ms_per_step": sp["pk_kernel_ms"][w][k] / args.profile_steps})
+
     if rank == 0:
         steps_per_sec = args.steps / elapsed
-        # roofline of the dominant kernel: algorithmic bytes of one launch / its average HIP-event duration.
-        # Normally ONE launch steps the tiles of both particle types (stats fused_launch); otherwise the
-        # white-particle launch is the dominant one and the yolk launch runs beside it.
         fused = bool(s1.get("fused_launch"))
-        algo_bytes = ALGO_BYTES_PER_PARTICLE_STEP * ((n_white + n_yolk) if fused else n_white)
-        achieved = algo_bytes / (kernel_ms_white * 1e-3) / 1e9 if kernel_ms_white > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and args.batches == 256 and world == 1:
+        packed = bool(s1["packed"][WHITE])
+        note = "592 B/particle/step byte model of SURVEY.md 8d; this path is bound by FP64 / integer instruction issue " \
+               "along the pair-dependency order, not by HBM bytes: see `traffic`, `valu` and DESIGN.md"
+        if packed and per_kernel:
+            white = [k for k in per_kernel if k["type"] == "white"]
+            kernel_ms = sum(k["ms_per_step"] for k in white)          # all launches stepping the white particles
+            dom = max(white, key=lambda k: k["ms_per_step"])
+            algo_bytes = ALGO_BYTES_PER_PARTICLE_STEP * n_white
+            kernel_name = "packed pipeline, white particles: %d launches per step (%s)" % (
+                round(sum(k["launches_per_step"] for k in white)), ", ".join(sorted({k["kernel"] for k in white})))
+            dominant = {"kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
+                        "share_of_kernel_ms": dom["ms_per_step"] / kernel_ms}
+        else:
+            kernel_ms = kernel_ms_white
+            algo_bytes = ALGO_BYTES_PER_PARTICLE_STEP * ((n_white + n_yolk) if fused else n_white)
+            kernel_name = "egg_step_kernel_multi* (one launch, white + yolk tiles)" if fused else "egg_step_kernel* (white launch)"
+            dominant = None
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic, valu = None, None
+        if os.path.exists(COUNTER_FILE) and world == 1:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                c = json.load(open(COUNTER_FILE)).get("%d_%d" % (args.batches, args.overlap))
+                if c:
+                    traffic, valu = c.get("hbm_bytes_per_step"), c.get("valu")
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "pair_solves_per_sec", "value": pairs / elapsed, "unit": "pair-solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,24 +286,26 @@ def main():
             "steps_per_sec": steps_per_sec,
             "constraint_solves_per_sec": (pairs + follows) / elapsed,
             "particles": int(total_particles),
-            "config": {"workload": ("BASELINE config 2: %d non-overlapping batches per GPU" % args.batches if args.overlap == 1 else
-                                    "BASELINE config 3 layout: %d batches per GPU, %d coincident per site" % (args.batches, args.overlap)) +
+            "config": {"workload": workload_name(args.batches, args.overlap) +
                                    " (white r=50, yolk r=15) on a %.0f px grid, default config, dt=1/60, 2 sub-steps x 3 "
                                    "collision passes" % site_pitch(args.overlap),
-                       "batches_per_gpu": args.batches, "particles_per_gpu": int(n_white + n_yolk),
+                       "batches_per_gpu": args.batches, "coincident_per_site": args.overlap,
+                       "particles_per_gpu": int(n_white + n_yolk),
                        "parallelism": "slab%d" % world, "tiles": s1["n_tiles"], "retiles": s1["retiles"] - s0["retiles"],
-                       "redo_steps": s1["redo_steps"] - s0["redo_steps"]},
+                       "redo_steps": s1["redo_steps"] - s0["redo_steps"], "path": "packed" if packed else "fused"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "egg_step_kernel_multi* (one launch, white + yolk tiles)" if fused else "egg_step_kernel* (white launch)",
-                         "kernel_ms": kernel_ms_white,
-                         "kernel_ms_yolk_launch": None if fused else kernel_ms_yolk, "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "592 B/particle/step byte model of SURVEY.md 8d; the fused kernel moves far fewer "
-                                 "HBM bytes and is bound by the serial pair-dependency chain in FP64, see DESIGN.md"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu,
+                         "kernel": kernel_name, "kernel_ms": kernel_ms, "dominant_kernel": dominant,
+                         "kernel_ms_timed_region": kernel_ms_white,
+                         "kernel_ms_yolk_stream": None if fused else kernel_ms_yolk,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernels": per_kernel, "note": note},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.batches)
-        elif world > 1:
+        if world == 1:
+            del h
+            if not args.no_latency:
+                out["latency_config2"] = latency_config2(torch, local_rank)
+            out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.batches, args.overlap)
+        else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
         sys.stdout.flush()

@@ -235,6 +235,10 @@ struct System {  // one particle type
     size_t pk_sort_words = 0;                // sorted-list words over all packed groups
     int pk_lev_cap = 255;                    // levels the tables hold; grows when a group's DAG is deeper
     bool pk_plan_dirty = true;
+    // EGG_OPT_TIMING = 2: one event pair per launch group of the packed pipeline, read back when the step is committed
+    struct PkStamp { hipEvent_t a, b; int kind, launches; };
+    std::vector<PkStamp> pk_stamps;
+    size_t pk_stamps_used = 0;
     EggStatus *h_status = nullptr;  // the most recent launch's status block inside stage_down (pinned)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1146,12 +1150,29 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
     }
     std::vector<EggPackedArgs> args(s.pk.size());
     for (size_t k = 0; k < s.pk.size(); ++k) fill_packed_args(h, which, s.pk[k], env, S, C, args[k]);
-    auto launch_all = [&](auto kernel_of, auto grid_of, auto block_of, auto lds_of) {
+    const bool stamp = h->opt_timing >= 2;
+    s.pk_stamps_used = 0;
+    auto stamp_begin = [&](int kind) -> System::PkStamp * {
+        if (!stamp) return nullptr;
+        if (s.pk_stamps_used == s.pk_stamps.size()) {
+            System::PkStamp ps{nullptr, nullptr, 0, 0};
+            if (hipEventCreate(&ps.a) != hipSuccess || hipEventCreate(&ps.b) != hipSuccess) return nullptr;
+            s.pk_stamps.push_back(ps);
+        }
+        System::PkStamp *ps = &s.pk_stamps[s.pk_stamps_used++];
+        ps->kind = kind;
+        ps->launches = (int)s.pk.size();
+        (void)hipEventRecord(ps->a, st);
+        return ps;
+    };
+    auto launch_all = [&](int kind, auto kernel_of, auto grid_of, auto block_of, auto lds_of) {
+        System::PkStamp *ps = stamp_begin(kind);
         for (size_t k = 0; k < s.pk.size(); ++k) {
             const PackedClass &pc = s.pk[k];
             hipLaunchKernelGGL(kernel_of(pc), dim3((unsigned)grid_of(pc)), dim3((unsigned)block_of(pc)), lds_of(pc), st, args[k]);
             h->stats.kernel_launches++;
         }
+        if (ps) (void)hipEventRecord(ps->b, st);
     };
     auto flat_grid = [](const PackedClass &pc) { return (pc.p_end - pc.p_begin + 255) / 256; };
     auto c256 = [](const PackedClass &) { return 256; };
@@ -1160,13 +1181,13 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
     auto tiles_of = [](const PackedClass &pc) { return pc.n_tiles; };
     auto groups_of = [](const PackedClass &pc) { return pc.n_groups; };
     if (s.pk_plan_dirty) {
-        launch_all([](const PackedClass &) { return egg_pk_plan_kernel; }, tiles_of, c64, no_lds);
+        launch_all(-1, [](const PackedClass &) { return egg_pk_plan_kernel; }, tiles_of, c64, no_lds);
         s.pk_plan_dirty = false;
     }
-    launch_all([](const PackedClass &) { return egg_pk_begin_kernel; }, flat_grid, c256, no_lds);
+    launch_all(EGG_PK_KIND_BEGIN, [](const PackedClass &) { return egg_pk_begin_kernel; }, flat_grid, c256, no_lds);
     int pass_seq = 0;
     for (int sub = 0; sub < S; ++sub) {
-        if (sub > 0) launch_all([](const PackedClass &) { return egg_pk_mid_kernel; }, flat_grid, c256, no_lds);
+        if (sub > 0) launch_all(EGG_PK_KIND_MID, [](const PackedClass &) { return egg_pk_mid_kernel; }, flat_grid, c256, no_lds);
         for (int c = 0; c < C; ++c, ++pass_seq) {
             const bool stale = c == 0 && sub > 0;  // hash lists and `collided` survive a sub-step boundary (L:1905-1912)
             for (EggPackedArgs &A : args) {
@@ -1174,25 +1195,28 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
                 A.substep = sub;
                 A.stale = stale ? 1 : 0;
             }
-            launch_all([&](const PackedClass &) { return stale ? egg_pk_lists_stale_kernel : egg_pk_lists_fresh_kernel; }, tiles_of,
+            launch_all(stale ? EGG_PK_KIND_LISTS_STALE : EGG_PK_KIND_LISTS_FRESH,
+                       [&](const PackedClass &) { return stale ? egg_pk_lists_stale_kernel : egg_pk_lists_fresh_kernel; }, tiles_of,
                        [](const PackedClass &pc) { return pc.threads_lists; }, [](const PackedClass &pc) { return pc.lds_lists; });
-            launch_all([](const PackedClass &pc) {
+            launch_all(EGG_PK_KIND_LEVELS, [](const PackedClass &pc) {
                            return pc.wd == 8 ? egg_pk_levels8_kernel : pc.wd == 16 ? egg_pk_levels16_kernel : egg_pk_levels64_kernel;
                        },
                        groups_of, c64, [](const PackedClass &pc) { return pc.lds_levels; });
-            launch_all([](const PackedClass &) { return egg_pk_sort_kernel; }, groups_of, c256,
+            launch_all(EGG_PK_KIND_SORT, [](const PackedClass &) { return egg_pk_sort_kernel; }, groups_of, c256,
                        [&](const PackedClass &) { return egg_align16((size_t)(s.pk_lev_cap + 2) * 4); });
-            launch_all([](const PackedClass &) { return egg_pk_exec_kernel; }, groups_of, c64,
+            launch_all(EGG_PK_KIND_EXEC, [](const PackedClass &) { return egg_pk_exec_kernel; }, groups_of, c64,
                        [](const PackedClass &pc) { return pc.lds_exec; });
         }
     }
-    launch_all([](const PackedClass &) { return egg_pk_end_kernel; }, tiles_of,
+    launch_all(EGG_PK_KIND_END, [](const PackedClass &) { return egg_pk_end_kernel; }, tiles_of,
                [](const PackedClass &pc) { return std::min(256, pc.threads_lists); }, no_lds);
     const int n_passes = std::min(S * C, EGG_PK_MAX_PASSES);
+    System::PkStamp *rs = stamp_begin(EGG_PK_KIND_REDUCE);
     for (size_t k = 0; k < s.pk.size(); ++k) {
         hipLaunchKernelGGL(egg_pk_reduce_kernel, dim3((unsigned)n_passes + 1), dim3(1024), 0, st, args[k], n_passes);
         h->stats.kernel_launches++;
     }
+    if (rs) (void)hipEventRecord(rs->b, st);
     HIP_TRY(h, hipGetLastError());
     return EGG_OK;
 }
@@ -1551,6 +1575,19 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
             h->stats.single_tile[w] = s.single_tile;
         }
         h->stats.last_step_kernel_ms = ms;
+        for (int w = 0; w < 2; ++w) {
+            System &s = h->sys[w];
+            h->stats.packed[w] = (int64_t)s.pk.size();
+            for (size_t k = 0; h->opt_timing >= 2 && k < s.pk_stamps_used; ++k) {
+                const System::PkStamp &ps = s.pk_stamps[k];
+                float t = 0;
+                if (ps.kind >= 0 && hipEventElapsedTime(&t, ps.a, ps.b) == hipSuccess) {
+                    h->stats.pk_kernel_ms[w][ps.kind] += (double)t;
+                    h->stats.pk_kernel_launches[w][ps.kind] += ps.launches;
+                }
+            }
+            s.pk_stamps_used = 0;
+        }
         if (h->opt_timing) {
             for (int w = 0; w < 2; ++w) h->stats.kernel_ms_sum[w] += h->stats.kernel_ms[w];
             h->stats.timed_steps++;
@@ -1713,6 +1750,10 @@ void egg_destroy(egg_handle *h) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.ev0) (void)hipEventDestroy(s.ev0);
         if (s.ev1) (void)hipEventDestroy(s.ev1);
+        for (auto &ps : s.pk_stamps) {
+            (void)hipEventDestroy(ps.a);
+            (void)hipEventDestroy(ps.b);
+        }
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     delete h;
@@ -2366,7 +2407,9 @@ int egg_set_option(egg_handle *h, int option, double value) {
             h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
             return EGG_OK;
         case EGG_OPT_TIMING:
-            h->opt_timing = value != 0;
+            h->opt_timing = value >= 2 ? 2 : (value != 0);
+            memset(h->stats.pk_kernel_ms, 0, sizeof h->stats.pk_kernel_ms);
+            memset(h->stats.pk_kernel_launches, 0, sizeof h->stats.pk_kernel_launches);
             h->stats.kernel_ms_sum[0] = h->stats.kernel_ms_sum[1] = 0;
             h->stats.timed_steps = 0;
             return EGG_OK;

@@ -185,6 +185,12 @@ typedef struct {
 } egg_environment;
 int egg_get_environment(egg_handle *h, int which, egg_environment *out);
 
+/* kernels of the packed pipeline (csrc/eggsim_packed.hip), for egg_stats.pk_kernel_ms */
+enum {
+    EGG_PK_KIND_BEGIN = 0, EGG_PK_KIND_MID, EGG_PK_KIND_LISTS_FRESH, EGG_PK_KIND_LISTS_STALE, EGG_PK_KIND_LEVELS,
+    EGG_PK_KIND_SORT, EGG_PK_KIND_EXEC, EGG_PK_KIND_END, EGG_PK_KIND_REDUCE, EGG_PK_N_KINDS
+};
+
 /* counters of the device path, cumulative since creation */
 typedef struct {
     int64_t steps;           /* _step calls executed */
@@ -203,6 +209,11 @@ typedef struct {
     int64_t max_pass_visits[2]; /* most pairs visited in one collision pass of the most recent _step, per type */
     double budget[2];           /* max_collision_fraction * N^2 of the most recent _step (L:1752-1753), per type */
     int64_t fused_launch;       /* 1 if the most recent _step ran both types' tiles in one launch (kernel_ms[0] == kernel_ms[1] is then that launch) */
+    int64_t packed[2];          /* launch classes of that type currently stepped by the packed pipeline (one launch per phase) */
+    /* EGG_OPT_TIMING = 2: HIP events around every launch of the packed pipeline, summed per kernel kind and type since the
+     * option was set: [type][kind], kind as in EGG_PK_KIND_* below */
+    double pk_kernel_ms[2][EGG_PK_N_KINDS];
+    int64_t pk_kernel_launches[2][EGG_PK_N_KINDS];
 } egg_stats;
 int egg_get_stats(egg_handle *h, egg_stats *out);
 
@@ -215,7 +226,7 @@ int egg_selftest_arith(egg_handle *h, int64_t n_operand_pairs, uint64_t seed, in
 enum {
     EGG_OPT_CLAIM_MARGIN_CELLS = 0, /* initial margin around an atom's cells when tiles are formed */
     EGG_OPT_TILE_TARGET_PARTICLES,  /* pack independent islands into tiles up to this size (0 = one island per tile; default 60: small islands share a wave) */
-    EGG_OPT_TIMING,                 /* 1: record HIP events around the step kernels */
+    EGG_OPT_TIMING,                 /* 1: record HIP events around the step kernels; 2: also around every launch of the packed pipeline (profiling runs: ~2 events per launch) */
     EGG_OPT_FORCE_SINGLE_TILE,      /* 1: always run each type as one tile (exact budget path) */
     EGG_OPT_THREADS_PER_PARTICLE,   /* lanes per particle: 0 automatic (3 for tiles that have a CU to themselves: visit lists built column-wise), 1 or 3 forced */
     EGG_OPT_SPIN_SLEEP,             /* -1 auto, 0 never, 1 always: idle dataflow waves sleep between polls */

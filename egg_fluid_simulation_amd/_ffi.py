@@ -103,6 +103,7 @@ _SIGNATURES = {
     "egg_prepare_step": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
     "egg_step_begin": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
     "egg_step_end": (C.c_int, [C.c_void_p, C.c_int32]),
+    "egg_step_peek_visits": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64 * 2), C.POINTER(C.c_double * 2)]),
     "egg_synchronize": (C.c_int, [C.c_void_p]),
     "egg_get_position": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "egg_get_positions_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

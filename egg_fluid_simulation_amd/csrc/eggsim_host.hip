@@ -2023,6 +2023,23 @@ int egg_step_end(egg_handle *h, int32_t commit) {
     return do_step(h, h->flight_delta, h->flight_s, h->flight_c, kEnd);
 }
 
+int egg_step_peek_visits(egg_handle *h, int64_t max_pass_visits[2], double budget[2]) {
+    if (!h || !max_pass_visits || !budget) return EGG_ERR_INVALID_ARGUMENT;
+    if (!h->in_flight) return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_step_peek_visits: no step in flight");
+    (void)hipSetDevice(h->device);
+    const double sub_delta = std::max(h->flight_delta / h->flight_s, h->sys[0].cfg.eps);
+    for (int w = 0; w < 2; ++w) {
+        System &s = h->sys[w];
+        max_pass_visits[w] = 0;
+        budget[w] = make_env(s.cfg, sub_delta, h->budget_particles[w] >= 0 ? h->budget_particles[w] : s.n).budget;
+        if (s.n == 0 || s.classes.empty()) continue;
+        HIP_TRY(h, wait_step(s.wait_stream ? s.wait_stream : s.stream));  // the status block was copied behind the kernels
+        const int np = std::min(h->flight_s * h->flight_c, EGG_MAX_PASSES);
+        for (int p = 0; p < np; ++p) max_pass_visits[w] = std::max(max_pass_visits[w], (int64_t)s.h_status->visits[p]);
+    }
+    return EGG_OK;
+}
+
 int egg_synchronize(egg_handle *h) {
     if (!h) return EGG_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(h->device);

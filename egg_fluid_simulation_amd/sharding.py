@@ -23,8 +23,13 @@ batches that provably cannot interact.  Sharding therefore works on whole batche
 
 Not covered: the collision budget's exact-mode (a type with so few particles that 0.05 N^2 visits
 can bind) needs all particles in one tile and therefore on one rank.  ShardedSimulationHandler.step
-watches for it (per-pass visits summed over ranks against the global budget) and raises EggError
-instead of stepping on.
+watches for it (per-pass visits of the step in flight, summed over ranks against the global budget,
+BEFORE the step is committed) and raises EggError instead of stepping on.
+
+Collectives: ONE small all_reduce per step (4 flags: conflict seen / budget suspect / batch strayed out of its
+slab's halo / a claim reaches past a whole neighbouring slab) tells every rank whether the launched step may be
+committed; everything else on the data path is neighbour point-to-point.  The rare hand-over round exchanges its
+plan with two all_gathers of fixed-shape integer tensors (no pickling).
 """
 import math
 
@@ -241,6 +246,9 @@ class ShardedSimulationHandler:
         self.radii = {}       # global id -> (white_radius, yolk_radius)
         self.next_gid = 1
         self.migrations = 0
+        self._elapsed = 0.0
+        self.interpolation_alpha = 0.0
+        self._budget_stale = True
         self._step_args = (1 / 60, 2, 3)
         lo, hi = layout.bounds(rank)
         self.exchange = BoundaryExchange(None, rank, self.world, lo, hi, group=group, halo_px=halo_px,
@@ -258,7 +266,7 @@ class ShardedSimulationHandler:
             lid = int(self.local.add_many_keyed([x], [y], [gid], white_radius, yolk_radius)[0])
             self.local_id[gid] = lid
             self.global_id[lid] = gid
-        self._sync_budget()
+        self._budget_stale = True  # summed over the ranks before the next step
         return gid
 
     def set_target_position(self, gid, x, y):
@@ -266,10 +274,25 @@ class ShardedSimulationHandler:
             self.local.set_target_position(self.local_id[gid], x, y)
 
     def update(self, delta, step_delta=None, n_substeps=None, n_collision_steps=None):
-        self._step_args = (1 / 60 if step_delta is None else step_delta, 2 if n_substeps is None else n_substeps,
-                           3 if n_collision_steps is None else n_collision_steps)
-        self.rebalance()
-        return self.local.update(delta, step_delta, n_substeps, n_collision_steps)
+        """The reference's fixed-step accumulator (simulation_handler.lua:199-216) around the exchanging step():
+        every `_step` gets its own claim exchange (the claims of one exchange cover one step only)."""
+        step_delta = 1 / 60 if step_delta is None else step_delta
+        n_substeps = 2 if n_substeps is None else int(math.ceil(n_substeps))
+        n_collision_steps = 3 if n_collision_steps is None else int(math.ceil(n_collision_steps))
+        if not (step_delta > 0) or n_substeps < 1 or n_collision_steps < 1:
+            raise EggError("[ERROR] In SimulationHandler.update: invalid step_delta / n_substeps / n_collision_steps")
+        self._elapsed = self._elapsed + delta
+        n_steps = 0
+        max_n_steps = max(4.0, 4 * math.ceil((1 / 60) / step_delta))
+        while self._elapsed >= step_delta:
+            self.step(step_delta, n_substeps, n_collision_steps)
+            self._elapsed = self._elapsed - step_delta
+            n_steps += 1
+            if n_steps > max_n_steps:  # death-spiral guard, L:208-213
+                self._elapsed = 0
+                break
+        self.interpolation_alpha = min(max(self._elapsed / step_delta, 0.0), 1.0)
+        return n_steps
 
     def step(self, delta=1 / 60, n_substeps=2, n_collision_steps=3):
         """One `_step` on every rank with the neighbour exchange hidden behind the kernels: post the
@@ -280,35 +303,49 @@ class ShardedSimulationHandler:
         if self.world == 1:
             self.local.step(delta, n_substeps, n_collision_steps)
             return 0
+        self._sync_budget()
         self.local.step_begin(delta, n_substeps, n_collision_steps)  # fixes this step's claims, launches the kernels
         self.exchange.post(claims_fixed=True)
         conflicts = self.exchange.finish(raise_on_conflict=False)
-        # strays (batches deep inside another slab) are balanced too, but never force a re-run by themselves.
-        # The second flag guards the collision budget (simulation_handler.lua:1657-1658): the reference
-        # counts the visits of ALL particles against 0.05 N^2, a rank only sees its own.  While every rank
-        # stays below budget / world the global count cannot bind; a rank above it (seen in the previous
-        # step) triggers the exact sum, and a binding budget across ranks is refused loudly.
-        st = self.local.stats()
-        suspect = any(v * self.world > max(1.0, math.ceil(b)) for v, b in zip(st["max_pass_visits"], st["budget"]))
-        flag = self.torch.tensor([1.0 if conflicts else 0.0, 1.0 if suspect else 0.0], dtype=self.torch.float64,
-                                 device=self.device)
+        ids, boxes = self.exchange.last_ids, self.exchange.last_boxes
+        lo, hi = self.exchange.slab_lo, self.exchange.slab_hi
+        halo = self.exchange.halo_px
+        stray = wide = False
+        if len(ids):
+            bl, bh = np.minimum(boxes[:, 0], boxes[:, 4]), np.maximum(boxes[:, 2], boxes[:, 6])
+            # strayed: wholly beyond the halo of this slab (it belongs to the neighbour now)
+            stray = bool(np.any((bh < lo - halo) & (self.rank > 0)) or np.any((bl > hi + halo) & (self.rank + 1 < self.world)))
+            # wide: a claim reaches past the whole neighbouring slab, where only the rank after next could see it
+            left_far = self.layout.cuts[self.rank - 1] if self.rank > 0 else -np.inf
+            right_far = self.layout.cuts[self.rank + 2] if self.rank + 2 <= self.world else np.inf
+            wide = bool(np.any(bl < left_far + halo) and self.rank > 1) or bool(np.any(bh > right_far - halo) and self.rank + 2 < self.world)
+        # The budget guard (simulation_handler.lua:1657-1658): the reference counts the visits of ALL particles
+        # against 0.05 N^2, a rank only sees its own.  While every rank stays below budget / world the global count
+        # cannot bind; a rank above it triggers the exact sum -- of THIS step, which is still uncommitted.
+        visits, budget = self.local.step_peek_visits()
+        suspect = any(v * self.world > max(1.0, math.ceil(b)) for v, b in zip(visits, budget))
+        flag = self.torch.tensor([1.0 if conflicts else 0.0, 1.0 if suspect else 0.0, 1.0 if stray else 0.0,
+                                  1.0 if wide else 0.0], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
         flags = flag.tolist()
         if flags[1] != 0.0:
-            tot = self.torch.tensor([float(v) for v in st["max_pass_visits"]], dtype=self.torch.float64,
-                                    device=self.device)
+            tot = self.torch.tensor([float(v) for v in visits], dtype=self.torch.float64, device=self.device)
             self.dist.all_reduce(tot, op=self.dist.ReduceOp.SUM)
-            bud = self.torch.tensor([float(b) for b in st["budget"]], dtype=self.torch.float64, device=self.device)
-            self.dist.all_reduce(bud, op=self.dist.ReduceOp.MAX)
-            for which, (v, b) in enumerate(zip(tot.tolist(), bud.tolist())):
+            for which, (v, b) in enumerate(zip(tot.tolist(), budget)):
                 if v > max(1.0, math.ceil(b)):
-                    self.local.step_end(False)
+                    self.local.step_end(False)  # nothing of the suspect step is kept
                     raise EggError("collision budget may bind across ranks (type %d: up to %d visits in a pass, "
                                    "budget %.2f): exact-budget mode needs all particles of the type on one rank"
                                    % (which, int(v), b))
+        if flags[3] != 0.0:
+            self.local.step_end(False)
+            raise EggError("a batch's claim for this step reaches past a whole neighbouring slab; slabs must be wider "
+                           "than the distance a batch travels in one step plus the halo")
         if flags[0] == 0.0:
             self.local.step_end(True)
-            return 0
+            # a batch that left its slab's halo without meeting anything is handed to the slab it is in before the
+            # next step, so that every batch is always known to the ranks on both sides of it
+            return self.rebalance() if flags[2] != 0.0 else 0
         self.local.step_end(False)
         moved = self.rebalance()
         self.local.step(delta, n_substeps, n_collision_steps)
@@ -319,12 +356,30 @@ class ShardedSimulationHandler:
         mine = {g: self.local.get_position(l) for g, l in self.local_id.items()}
         if self.world == 1:
             return mine
-        out = [None] * self.world
-        self.dist.all_gather_object(out, mine)
+        rec = np.array([[g, p[0], p[1]] for g, p in sorted(mine.items())], dtype=np.float64).reshape(-1, 3)
         merged = {}
-        for d in out:
-            merged.update(d)
+        for part in self._all_gather_rows(rec):
+            for g, x, y in part:
+                merged[int(g)] = (float(x), float(y))
         return merged
+
+    def _all_gather_rows(self, rows):
+        """all_gather of a [n, k] float64 array with a different n on every rank: counts first, then the rows padded to
+        the largest count (two fixed-shape tensor collectives, nothing is pickled)"""
+        torch, dist = self.torch, self.dist
+        rows = np.asarray(rows, dtype=np.float64)
+        k = rows.shape[1]
+        cnt = torch.tensor([float(rows.shape[0])], dtype=torch.float64, device=self.device)
+        counts = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(counts, cnt)
+        counts = [int(c.item()) for c in counts]
+        m = max(1, max(counts))
+        buf = torch.zeros(m * k, dtype=torch.float64, device=self.device)
+        if rows.shape[0]:
+            buf[:rows.size] = torch.from_numpy(rows.reshape(-1)).to(self.device)
+        parts = [torch.zeros(m * k, dtype=torch.float64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(parts, buf)
+        return [p.cpu().numpy()[:c * k].reshape(c, k) for p, c in zip(parts, counts)]
 
     def particles(self, which):
         """{global id: (x[n], y[n])} of this rank's batches"""
@@ -343,15 +398,18 @@ class ShardedSimulationHandler:
         return gids, boxes
 
     def _sync_budget(self):
-        # the budget 0.05 N^2 counts the particles of ALL ranks (simulation_handler.lua:1752-1753)
+        """the budget 0.05 N^2 counts the particles of ALL ranks (simulation_handler.lua:1752-1753): the sum of what the
+        handlers actually hold (hand-overs do not change it; adds and removes mark it stale)"""
+        if self.world == 1 or not self._budget_stale:
+            return
         from . import _ffi
-        nw = ny = 0
-        for g, (wr, yr) in self.radii.items():
-            nw += int(math.ceil((wr * wr) / 16.0))
-            ny += int(math.ceil((yr * yr) / 16.0))
-        if self.world > 1:
-            self.local.set_option(_ffi.OPT_BUDGET_PARTICLES_WHITE, nw)
-            self.local.set_option(_ffi.OPT_BUDGET_PARTICLES_YOLK, ny)
+        nw, ny = self.local.get_n_particles()
+        tot = self.torch.tensor([float(nw), float(ny)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(tot, op=self.dist.ReduceOp.SUM)
+        nw, ny = (int(v) for v in tot.tolist())
+        self.local.set_option(_ffi.OPT_BUDGET_PARTICLES_WHITE, nw)
+        self.local.set_option(_ffi.OPT_BUDGET_PARTICLES_YOLK, ny)
+        self._budget_stale = False
 
     def _send_batch(self, gid, to):
         torch, dist = self.torch, self.dist
@@ -410,8 +468,10 @@ class ShardedSimulationHandler:
                 elif self.rank + 1 < self.world and min(b[0], b[4]) > hi + self.exchange.halo_px:
                     to_right.add(g)
             # everyone learns every plan: how many batches arrive from whom, and the new owner table
-            gathered = [None] * self.world
-            dist.all_gather_object(gathered, (sorted(to_left), sorted(to_right), sorted(want_right)))
+            rows = [[0.0, g] for g in sorted(to_left)] + [[1.0, g] for g in sorted(to_right)] + [[2.0, g] for g in sorted(want_right)]
+            parts = self._all_gather_rows(np.array(rows, dtype=np.float64).reshape(-1, 2))
+            gathered = [([int(g) for k, g in part if k == 0.0], [int(g) for k, g in part if k == 1.0],
+                         [int(g) for k, g in part if k == 2.0]) for part in parts]
             plan = []
             for r, (l, rr, _w) in enumerate(gathered):
                 wanted = set(gathered[r - 1][2]) if r > 0 else set()
@@ -420,7 +480,11 @@ class ShardedSimulationHandler:
             to_left, to_right = set(plan[self.rank][0]), set(plan[self.rank][1])
             n_moves = sum(len(l) + len(r) for l, r in plan)
             if n_moves == 0:
-                if conflicts:
+                # nothing left to move anywhere: every rank decides TOGETHER whether that is a clean end (a rank that
+                # raised alone would leave the others hanging in their next collective)
+                bad = torch.tensor([1.0 if conflicts else 0.0], dtype=torch.float64, device=self.device)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if bad.item() != 0.0:
                     raise SlabConflict("rank %d: unresolved cross-slab pairs %s" % (self.rank, conflicts[:3]))
                 return moved_total
             # even ranks send first, odd ranks receive first: neighbour pairs never both block in send

@@ -317,6 +317,13 @@ class SimulationHandler:
     def step_end(self, commit=True):
         self._check(self._lib.egg_step_end(self._h, 1 if commit else 0))
 
+    def step_peek_visits(self):
+        """(max visits in one pass per type, budget per type) of the step launched with step_begin, before it is
+        committed (see egg_step_peek_visits)"""
+        v, b = (C.c_int64 * 2)(), (C.c_double * 2)()
+        self._check(self._lib.egg_step_peek_visits(self._h, C.byref(v), C.byref(b)))
+        return list(v), list(b)
+
     def prepare_step(self, step_delta=1 / 60, n_substeps=2, n_collision_steps=3):
         """form the tiles/claims of the next step without running it (multi-GPU exchange)"""
         self._check(self._lib.egg_prepare_step(self._h, float(step_delta), int(n_substeps), int(n_collision_steps)))

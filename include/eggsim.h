@@ -135,6 +135,11 @@ int egg_prepare_step(egg_handle *h, double step_delta, int32_t n_substeps, int32
  * discards the launched step (the state is double-buffered, nothing was committed). */
 int egg_step_begin(egg_handle *h, double delta, int32_t n_substeps, int32_t n_collision_steps);
 int egg_step_end(egg_handle *h, int32_t commit);
+/* Between egg_step_begin and egg_step_end: waits for the launched step and reports, per type, the most pairs it
+ * visited in one collision pass and the budget 0.05 N^2 it is priced at (L:1657-1658, L:1752-1753) -- BEFORE
+ * anything is committed.  Multi-GPU: the reference counts the visits of ALL particles against the budget, a rank
+ * sees its own; the ranks add these up and discard the step when the sum could have tripped the early return. */
+int egg_step_peek_visits(egg_handle *h, int64_t max_pass_visits[2], double budget[2]);
 /* blocks until all device work of this handle is finished */
 int egg_synchronize(egg_handle *h);
 

@@ -99,3 +99,178 @@ def test_boundary_exchange_two_ranks_gloo(scenario):
         assert res[0][0] == res[1][0] == "conflict"
         assert res[0][1][1][0] == [100] and res[1][1][0][0] == [3]
         assert res[0][1][1][1][0][0] == pytest.approx(1000.0 + 40 - 56)  # white box lo_x of the ghost
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ShardedSimulationHandler's protocol on the CPU, four ranks: a stand-in for the device handler (each batch is a box
+# that walks towards its target at a fixed speed; "particle state" is its centre) behind the real exchange /
+# hand-over code over gloo.  A batch column is driven across TWO cuts, and the scenario is arranged so that the
+# middle rank receives from BOTH neighbours in one hand-over round.
+
+class _FakeHandler:
+    """the part of SimulationHandler's surface sharding.py uses; no GPU"""
+    SPEED = 25.0
+
+    def __init__(self):
+        self.b = {}       # local id -> dict(key, x, y, tx, ty)
+        self.next_id = 1
+        self.flight = None
+        self.imports = []  # (round marker, key) for the test
+        self.options = {}
+
+    def add_many_keyed(self, xs, ys, keys, wr=None, yr=None):
+        ids = []
+        for x, y, k in zip(xs, ys, keys):
+            self.b[self.next_id] = dict(key=int(k), x=float(x), y=float(y), tx=float(x), ty=float(y))
+            ids.append(self.next_id)
+            self.next_id += 1
+        return np.array(ids)
+
+    def set_target_position(self, i, x, y):
+        self.b[i]["tx"], self.b[i]["ty"] = float(x), float(y)
+
+    def _advance(self):
+        new = {}
+        for i, v in self.b.items():
+            dx, dy = v["tx"] - v["x"], v["ty"] - v["y"]
+            d = (dx * dx + dy * dy) ** 0.5
+            s = min(1.0, self.SPEED / d) if d > 0 else 0.0
+            new[i] = (v["x"] + s * dx, v["y"] + s * dy)
+        return new
+
+    def step_begin(self, *a):
+        assert self.flight is None
+        self.flight = self._advance()
+
+    def step_end(self, commit=True):
+        assert self.flight is not None
+        if commit:
+            for i, (x, y) in self.flight.items():
+                self.b[i]["x"], self.b[i]["y"] = x, y
+        self.flight = None
+
+    def step(self, *a):
+        self.step_begin()
+        self.step_end(True)
+
+    def step_peek_visits(self):
+        return [0, 0], [1e9, 1e9]
+
+    def prepare_step(self, *a):
+        pass
+
+    def get_claims(self, ids):
+        # the claim covers where the batch is and where it will be after the step, +- 56 px
+        nxt = self._advance()
+        out = []
+        for i in ids:
+            v, (nx, ny) = self.b[int(i)], nxt[int(i)]
+            box = [min(v["x"], nx) - 56, min(v["y"], ny) - 56, max(v["x"], nx) + 56, max(v["y"], ny) + 56]
+            out.append(box + box)
+        return np.array(out, dtype=np.float64).reshape(len(ids), 8), (8.0, 12.0)
+
+    def export_batch(self, i):
+        v = self.b[i]
+        info = dict(key=v["key"], target_x=v["tx"], target_y=v["ty"], white_radius=50.0, yolk_radius=15.0, n_white=1, n_yolk=1)
+        st = np.zeros((9, 1))
+        st[0, 0], st[1, 0] = v["x"], v["y"]
+        return info, st, st.copy()
+
+    def import_batch(self, info, ws, ys):
+        i = self.next_id
+        self.next_id += 1
+        self.b[i] = dict(key=int(info["key"]), x=float(ws[0, 0]), y=float(ws[1, 0]), tx=info["target_x"], ty=info["target_y"])
+        self.imports.append(int(info["key"]))
+        return i
+
+    def remove(self, i):
+        del self.b[i]
+
+    def get_position(self, i):
+        return (self.b[i]["x"], self.b[i]["y"])
+
+    def get_n_particles(self):
+        return (len(self.b), len(self.b))
+
+    def set_option(self, k, v):
+        self.options[k] = v
+
+    def stats(self):
+        return dict(max_pass_visits=[0, 0], budget=[1e9, 1e9])
+
+
+def _scenario4():
+    """cuts at 500 / 1000 / 1500.  Batch 1 (slab 0) runs right through slab 1 into slab 2; batch 2 (slab 2) runs left
+    into slab 1 where it meets batch 3 (slab 1, standing still).  Batch 1's target is set so that it has strayed out of
+    slab 0's halo exactly when 2 and 3 first come within reach: rank 1 then receives batch 1 from rank 0 (stray) and
+    batch 2 from rank 2 (conflict: the lower rank steps the pair) in one hand-over round.  Batches 4-7 stand still."""
+    start = {1: (380.0, 100.0), 2: (1180.0, 400.0), 3: (760.0, 400.0), 4: (100.0, 700.0), 5: (1300.0, 700.0),
+             6: (1800.0, 100.0), 7: (1700.0, 700.0)}
+    goal = {1: (1400.0, 100.0), 2: (880.0, 400.0)}
+    return start, goal
+
+
+def _worker4(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from egg_fluid_simulation_amd.sharding import ShardedSimulationHandler, SlabLayout
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        start, goal = _scenario4()
+        sh = ShardedSimulationHandler(SlabLayout([0.0, 500.0, 1000.0, 1500.0, 2000.0]), rank, dist, _FakeHandler, device="cpu")
+        gids = [sh.add(*start[g]) for g in sorted(start)]
+        assert gids == sorted(start)
+        rounds = []  # per step: keys this rank imported
+        for k in range(40):
+            for g, t in goal.items():
+                sh.set_target_position(g, *t)
+            before = len(sh.local.imports)
+            if k % 3 == 2:
+                assert sh.update(1 / 60) == 1
+            else:
+                sh.step(1 / 60)
+            rounds.append(sh.local.imports[before:])
+        q.put((rank, "ok", sh.positions(), dict(sh.owner), sorted(sh.local_id), rounds, sh.migrations))
+    except Exception:
+        import traceback
+        q.put((rank, "error: " + traceback.format_exc(), None, None, None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_ranks_hand_over_from_both_sides_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        out = q.get(timeout=180)
+        assert out[1] == "ok", out[1]
+        res[out[0]] = out
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # the same dynamics in one process: every batch walks towards its target on its own
+    start, goal = _scenario4()
+    ref = _FakeHandler()
+    ids = ref.add_many_keyed([start[g][0] for g in sorted(start)], [start[g][1] for g in sorted(start)], sorted(start))
+    for k in range(40):
+        for g, t in goal.items():
+            ref.set_target_position(int(ids[g - 1]), *t)
+        ref.step()
+    want = {g: ref.get_position(int(ids[g - 1])) for g in sorted(start)}
+    for r in range(4):
+        assert res[r][2] == want, r                      # every rank gathers the same, correct positions
+        assert res[r][3] == res[0][3]                    # and the same owner table
+    held = sorted(g for r in range(4) for g in res[r][4])
+    assert held == sorted(start)                          # no batch lost or duplicated
+    owner = res[0][3]
+    assert owner[1] == 2 and owner[2] == 1 and owner[3] == 1  # batch 1 crossed two cuts; 2 joined 3 on the lower rank
+    both = [rd for rd in res[1][5] if 1 in rd and 2 in rd]
+    assert both, "rank 1 must have received from both neighbours in one hand-over round: %s" % res[1][5]
+    assert res[0][6] == res[3][6] >= 3                   # everyone counts the same migrations

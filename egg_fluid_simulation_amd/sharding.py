@@ -453,20 +453,39 @@ class ShardedSimulationHandler:
             ids, boxes = self.exchange.last_ids, self.exchange.last_boxes
             lo, hi = self.exchange.slab_lo, self.exchange.slab_hi
             to_left, to_right, want_right = set(), set(), set()
+            # batches move as whole ISLANDS (local batches chained by claims less than a cell apart): one member going
+            # alone would meet its island-mates across the cut in the next round and come straight back
+            island = {int(g): int(g) for g in ids}
+
+            def find(g):
+                while island[g] != g:
+                    island[g] = island[island[g]]
+                    g = island[g]
+                return g
+
+            for a, b in self.exchange.conflicts(ids, boxes, ids, boxes, self.exchange.interact_px):
+                if a != b:
+                    ra, rb = find(int(a)), find(int(b))
+                    if ra != rb:
+                        island[max(ra, rb)] = min(ra, rb)
+            members = {}
+            for g in island:
+                members.setdefault(find(g), []).append(g)
             for lid_g, ghost, ghost_rank in conflicts:
                 if ghost_rank < self.rank:
-                    to_left.add(int(lid_g))   # the lower rank steps the pair
+                    to_left.update(members[find(int(lid_g))])   # the lower rank steps the pair
                 else:
                     want_right.add(int(ghost))  # its owner may not see my batch: ask for it
-            in_conflict = {int(c[0]) for c in conflicts}
-            for g, b in zip(ids, boxes):
-                g = int(g)
-                if g in in_conflict:
+            in_conflict = {find(int(c[0])) for c in conflicts}
+            box_of = {int(g): b for g, b in zip(ids, boxes)}
+            for root, gs in members.items():
+                if root in in_conflict:
                     continue
-                if self.rank > 0 and max(b[2], b[6]) < lo - self.exchange.halo_px:
-                    to_left.add(g)
-                elif self.rank + 1 < self.world and min(b[0], b[4]) > hi + self.exchange.halo_px:
-                    to_right.add(g)
+                # strayed: the whole island lies beyond the halo of this slab -> it belongs to the slab it is in
+                if self.rank > 0 and all(max(box_of[g][2], box_of[g][6]) < lo - self.exchange.halo_px for g in gs):
+                    to_left.update(gs)
+                elif self.rank + 1 < self.world and all(min(box_of[g][0], box_of[g][4]) > hi + self.exchange.halo_px for g in gs):
+                    to_right.update(gs)
             # everyone learns every plan: how many batches arrive from whom, and the new owner table
             rows = [[0.0, g] for g in sorted(to_left)] + [[1.0, g] for g in sorted(to_right)] + [[2.0, g] for g in sorted(want_right)]
             parts = self._all_gather_rows(np.array(rows, dtype=np.float64).reshape(-1, 2))

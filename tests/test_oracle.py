@@ -9,7 +9,10 @@ import math
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, load_golden, replay_golden
+import os
+import sys
+
+from conftest import GOLDEN_CASES, ROOT, load_golden, replay_golden
 
 WHITE, YOLK = 0, 1
 
@@ -216,3 +219,45 @@ def test_remove_preserves_order(oracle_mod):
     for _ in range(3):
         o.update(1 / 60)
     assert o.get_position(ids[2])[0] == pytest.approx(200, abs=5)
+
+
+def test_oracle_matches_reference_held_vectors(oracle_mod):
+    """Pins the oracle to the REFERENCE: tests/golden_lua/*.npz are produced by the reference itself under LuaJIT
+    (oracle/lua/gen_golden.lua + love_stub.lua, imported by oracle/lua/import_golden.py).  No Lua interpreter exists
+    in this pipeline, so until someone runs that script elsewhere the directory is empty, this test is skipped and
+    parity stays "unpinned" (SURVEY.md 8c)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden_lua", "*.npz")))
+    if not files:
+        pytest.skip("no reference-held vectors (tests/golden_lua is empty): parity unpinned")
+    for path in files:
+        name = os.path.splitext(os.path.basename(path))[0]
+        ref, g = np.load(path), load_golden(name)
+        o = oracle_mod.Oracle()
+
+        def check(step, tag, arr):
+            assert np.array_equal(arr, ref["%s_step%d" % (tag, step)]), (name, step, tag)
+
+        ids = replay_golden(g, o, lambda sim, w: np.array([sim.field(w, f) for f in ("x", "y", "vx", "vy")]), check)
+        last = int(g["snap_steps"][-1])
+        assert np.array_equal(np.array([o.get_position(i) for i in ids]), ref["centroid_step%d" % last])
+
+
+def test_lua_generator_covers_the_python_generator_cases():
+    """oracle/lua/gen_golden.lua (not runnable here) must dump the same cases with the same parameters as
+    oracle/gen_golden.py, so that its vectors drop into the same tests"""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import gen_golden
+    lua = open(os.path.join(ROOT, "oracle", "lua", "gen_golden.lua")).read()
+    for name, (centers, moving, n_steps, snaps, S, C) in gen_golden.CASES.items():
+        m = re.search(r'\{ "%s", \{(.*?)\}, (true|false), (\d+), \{(.*?)\}, (\d+), (\d+) \}' % name, lua)
+        assert m, name
+        got_centers = [tuple(float(v) for v in c.split(",")) for c in re.findall(r"\{ ([-\d., ]+) \}", m.group(1))]
+        assert got_centers == [tuple(map(float, c)) for c in centers], name
+        assert (m.group(2) == "true") == moving and int(m.group(3)) == n_steps
+        assert [int(v) for v in m.group(4).split(",")] == snaps and (int(m.group(5)), int(m.group(6))) == (S, C)
+    stub = open(os.path.join(ROOT, "oracle", "lua", "love_stub.lua")).read()
+    for api in ("getSupported", "getTextureFormats", "newCanvas", "newMesh", "newShader", "validateShader", "getInfo",
+                "getVersion", "getRendererInfo"):  # what construction and _step call (SURVEY.md 8c, last row)
+        assert api in stub, api

@@ -207,6 +207,8 @@ struct System {  // one particle type
     DevBuf<unsigned char> d_meta;
     size_t meta_off_ty = 0, meta_off_fd = 0, meta_off_claim = 0, meta_off_tbegin = 0, meta_off_tatoms = 0;
     bool out_copied = false;  // stage_down holds this launch's boxes / travel
+    bool eager_boxes = true;  // copy the atoms' boxes / travel back behind every step (the scene re-tiles every step: moving
+                              // targets); a scene at rest fetches them only when a tiling needs them
     DevBuf<unsigned char> d_scratch;
     std::vector<LaunchClass> classes;
     int margin = 2;
@@ -1057,7 +1059,8 @@ void fill_args(egg_handle *h, int which, const LaunchClass &lc, const Env &env, 
 int launch_epilogue(egg_handle *h, int which, hipStream_t stream) {
     System &s = h->sys[which];
     const size_t na = s.atoms.size();
-    const bool with_boxes = na && na <= (size_t)4 << 20;  // 32 B per atom; beyond that the boxes are fetched when a tiling needs them
+    // 32 B per atom; a scene that is not re-tiling (and a very large one) fetches the boxes when a tiling needs them
+    const bool with_boxes = na && na <= (size_t)4 << 20 && s.eager_boxes;
     const size_t bytes = (2 * kStatInts + (with_boxes ? 8 * na : 0)) * sizeof(int32_t);
     HIP_TRY(h, s.stage_down.reserve(bytes));
     HIP_TRY(h, hipMemcpyAsync(s.stage_down.p, s.d_out.p, bytes, hipMemcpyDeviceToHost, stream));
@@ -1573,6 +1576,7 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                 }
             }
             h->stats.single_tile[w] = s.single_tile;
+            s.eager_boxes = s.tiling_dirty || s.claims_stale;  // the next step re-tiles: so will the one after, probably
         }
         h->stats.last_step_kernel_ms = ms;
         for (int w = 0; w < 2; ++w) {
@@ -2108,6 +2112,7 @@ int egg_get_bounds_many(egg_handle *h, int64_t n, const int64_t *ids, double *lo
         if (rc != EGG_OK) return rc;
         cell[w] = cell_size_of(s.cfg);
         const size_t na = s.atoms.size();
+        if (!s.tiling_dirty && s.h_claim.size() == na) continue;  // the claims of the formed tiles answer the query below
         if (h->in_flight && !s.aabb_valid && na)  // the running step kernel owns the device-side box buffer
             return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_get_bounds_many: cell boxes are not available while a step is in flight");
         if (!s.aabb_valid && s.aabb_on_device && s.tiled_cell_size == cell[w]) {

@@ -149,9 +149,10 @@ struct EggPackedArgs {
     // entries self | slow << 15 | other << 16 (tile-local indices) of every particle as `self`, ascending
     uint32_t *lists;
     uint16_t *lvl;             // level of each stream entry
-    // per group, `sort_cap` words each: the group's pairs sorted by level, every level padded to a multiple of 64
-    // entries (bit 31 marks a pair, padding is 0), indices group-local: the executor's chunk c is words [64 c, 64 c + 64)
+    // per group, `sort_cap` words each: the group's pairs sorted by level (bit 31 set, indices group-local), and its
+    // work list of `chunk_cap` words: chunk c = first word | (pairs - 1) << 26, at most 64 pairs of ONE level, levels ascending
     uint32_t *sorted;
+    uint32_t *chunks;
     int32_t *grp_nchunks;      // [n_groups]
     uint32_t *lev_start;       // [n_groups][lev_cap + 2] first slot of every level in the group's sorted list
     int32_t *grp_nlev;         // [n_groups]
@@ -159,7 +160,7 @@ struct EggPackedArgs {
     int32_t *tile_visits;      // [EGG_PK_MAX_PASSES][n_tiles] n_collided of each pass (L:1657)
     int32_t *tile_need;        // [EGG_PK_MAX_PASSES][n_tiles] visit entries each pass needed (list capacity check)
     int32_t *tile_slack;       // [n_tiles]
-    int32_t lcap, scap, lev_cap, sort_cap;
+    int32_t lcap, scap, lev_cap, sort_cap, chunk_cap;
     // LDS geometry of egg_pk_lists
     int32_t nmax, amax, ccap, use_grid, stage_cap;
     // environment

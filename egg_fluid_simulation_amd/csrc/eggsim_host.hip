@@ -48,6 +48,7 @@ extern "C" __global__ void egg_pk_levels16_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels64_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_exec_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_sort_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_sort_direct_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_end_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_reduce_kernel(EggPackedArgs A, int n_passes);
 extern "C" __global__ void egg_atom_bounds_kernel(const double *, const double *, const int32_t *, const int32_t *,
@@ -162,8 +163,11 @@ struct PackedClass {
     int wd = 8;             // lanes per tile in the level walk
     int lcap = 0, scap = 0;  // visit entries / stream words (entries + one header per particle) a tile may have
     int stage_cap = 0;       // partners per particle the list kernel's counting pass keeps in LDS
-    int sort_cap = 0;        // words of a group's sorted list (every level padded to a multiple of 64)
+    int sort_cap = 0;        // words of a group's sorted list
     size_t sort_base = 0;
+    int chunk_cap = 0;       // chunk descriptors per group
+    size_t chunk_base = 0;
+    size_t lds_sort = 0;     // 0: the sort kernel scatters straight into global memory
     size_t entry_base = 0;  // first stream word of the class in the per-entry arrays
     size_t lds_lists = 0, lds_levels = 0, lds_exec = 0;
     int threads_lists = 64;
@@ -229,7 +233,8 @@ struct System {  // one particle type
     std::vector<int32_t> pk_meta_host;       // tile_p0 / grp_tile0 of every packed class
     DevBuf<int32_t> pk_meta, pk_src, pk_atom, pk_tile, pk_nchunks;
     DevBuf<double> pk_pos, pk_prev, pk_wr;
-    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_levstart;
+    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_levstart, pk_chunks;
+    size_t pk_chunk_words = 0;
     DevBuf<uint16_t> pk_lvl, pk_aslot;
     size_t pk_meta_claims = 0;               // offset (ints) of the tile claims inside pk_meta
     int pk_n = 0, pk_tiles = 0, pk_groups = 0;
@@ -273,7 +278,7 @@ struct egg_handle {
     int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
     int opt_spin_sleep = -1;  // -1 auto
     int opt_packed = -1;      // packed pipeline: -1 automatic (large scenes), 0 never, 1 every eligible class
-    int opt_group_particles = 1280;  // particles one wave of the packed executor keeps in LDS (16 B each)
+    int opt_group_particles = 1280;  // particles one wave of the packed executor keeps in LDS (16 B each: 8 such waves fill a CU's 160 KiB)
     int opt_force_global_state = 0;  // test hook: run every tile through the global-memory-state kernel  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
     hipDeviceProp_t prop{};
     size_t lds_limit = 64 * 1024;  // dynamic LDS a step-kernel workgroup may use
@@ -815,6 +820,7 @@ int retile(egg_handle *h, int which) {
     s.pk_n = s.pk_tiles = s.pk_groups = 0;
     s.pk_entries = 0;
     s.pk_sort_words = 0;
+    s.pk_chunk_words = 0;
     {
         // automatic: scenes large enough that the chip is full of tiles whatever the kernel (the fused kernel's
         // latency per step is lower while every tile has a CU almost to itself); judged on the white particles so
@@ -889,14 +895,19 @@ int retile(egg_handle *h, int which) {
             }
             const int per_group = (lc.n_tiles + pc.n_groups - 1) / pc.n_groups;
             pc.wd = per_group >= 8 ? 8 : 16;
-            pc.lds_exec = (size_t)pc.max_group_particles * 16;
             pc.lds_levels = egg_pk_levels_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd);
-            const size_t sort_words = (size_t)max_tiles_in_group * (size_t)pc.scap + 64 * (size_t)s.pk_lev_cap + 64;
-            if (pc.lds_exec > h->lds_limit || pc.lds_levels > h->lds_limit || sort_words >= ((size_t)1 << 30)) {
+            const size_t sort_words = (size_t)max_tiles_in_group * (size_t)pc.scap + 64;
+            pc.chunk_cap = (int)std::min<size_t>(sort_words / 64 + (size_t)s.pk_lev_cap + 8, (size_t)1 << 28);
+            pc.lds_exec = (size_t)pc.max_group_particles * 16;
+            pc.lds_sort = egg_align16((size_t)(s.pk_lev_cap + 2) * 4) + sort_words * 4;
+            if (pc.lds_sort > 64 * 1024) pc.lds_sort = 0;
+            if (pc.lds_exec > h->lds_limit || pc.lds_levels > h->lds_limit || sort_words >= ((size_t)1 << 26)) {
                 s.pk_meta_host.resize(meta_mark);
                 continue;
             }
             pc.sort_cap = (int)sort_words;
+            pc.chunk_base = s.pk_chunk_words;
+            s.pk_chunk_words += (size_t)pc.n_groups * (size_t)pc.chunk_cap;
             lc.packed = (int)s.pk.size();
             s.pk_n = pn;
             s.pk_tiles += lc.n_tiles;
@@ -926,6 +937,7 @@ int retile(egg_handle *h, int which) {
             HIP_TRY(h, s.pk_lists.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_lvl.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_sorted.reserve(s.pk_sort_words + 64, false, s.stream));
+            HIP_TRY(h, s.pk_chunks.reserve(s.pk_chunk_words + 64, false, s.stream));
             HIP_TRY(h, s.pk_nchunks.reserve(2 * ng + 8, false, s.stream));
             HIP_TRY(h, s.pk_levstart.reserve(ng * ((size_t)s.pk_lev_cap + 2) + 64, false, s.stream));
             HIP_TRY(h, s.pk_tile.reserve(nt * (2 + 2 * EGG_PK_MAX_PASSES) + 4, false, s.stream));
@@ -1114,6 +1126,7 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.lists = s.pk_lists.p + pc.entry_base;
     A.lvl = s.pk_lvl.p + pc.entry_base;
     A.sorted = s.pk_sorted.p + pc.sort_base;
+    A.chunks = s.pk_chunks.p + pc.chunk_base;
     A.grp_nchunks = s.pk_nchunks.p + pc.group_base;
     A.grp_nlev = s.pk_nchunks.p + s.pk_groups + pc.group_base;
     A.lev_start = s.pk_levstart.p + (size_t)pc.group_base * ((size_t)s.pk_lev_cap + 2);
@@ -1126,6 +1139,7 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.scap = pc.scap;
     A.lev_cap = s.pk_lev_cap;
     A.sort_cap = pc.sort_cap;
+    A.chunk_cap = pc.chunk_cap;
     A.stage_cap = pc.stage_cap;
     A.nmax = lc.nmax;
     A.amax = lc.amax;
@@ -1205,8 +1219,9 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
                            return pc.wd == 8 ? egg_pk_levels8_kernel : pc.wd == 16 ? egg_pk_levels16_kernel : egg_pk_levels64_kernel;
                        },
                        groups_of, c64, [](const PackedClass &pc) { return pc.lds_levels; });
-            launch_all(EGG_PK_KIND_SORT, [](const PackedClass &) { return egg_pk_sort_kernel; }, groups_of, c256,
-                       [&](const PackedClass &) { return egg_align16((size_t)(s.pk_lev_cap + 2) * 4); });
+            launch_all(EGG_PK_KIND_SORT, [](const PackedClass &pc) { return pc.lds_sort ? egg_pk_sort_kernel : egg_pk_sort_direct_kernel; },
+                       groups_of, c256,
+                       [&](const PackedClass &pc) { return pc.lds_sort ? pc.lds_sort : egg_align16((size_t)(s.pk_lev_cap + 2) * 4); });
             launch_all(EGG_PK_KIND_EXEC, [](const PackedClass &) { return egg_pk_exec_kernel; }, groups_of, c64,
                        [](const PackedClass &pc) { return pc.lds_exec; });
         }
@@ -1709,7 +1724,8 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
         if (e == hipSuccess)
             for (const void *f : {(const void *)egg_pk_lists_fresh_kernel, (const void *)egg_pk_lists_stale_kernel,
                                   (const void *)egg_pk_levels8_kernel, (const void *)egg_pk_levels16_kernel,
-                                  (const void *)egg_pk_levels64_kernel, (const void *)egg_pk_exec_kernel})
+                                  (const void *)egg_pk_levels64_kernel, (const void *)egg_pk_exec_kernel,
+                                  (const void *)egg_pk_sort_kernel})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess) {
             h->lds_limit = want;

@@ -555,21 +555,30 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
         atomicMax(&A.status->max_level, maxlev);
     }
     const int nlev = min(maxlev, lev_cap);
-    // first slot of every level in the group's sorted list; every level is padded to whole chunks of 64 (level 0 is empty)
+    // first slot of every level in the group's sorted list (level 0 is empty), and the executor's work list: chunks of
+    // at most 64 pairs, each inside one level, levels ascending
     uint32_t *lstart = A.lev_start + (size_t)g * (lev_cap + 2);
-    uint32_t carry = 0;
+    uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
+    uint32_t carry = 0, ccarry = 0;
     for (int b0 = 1; b0 <= nlev; b0 += 64) {
         const int L = b0 + lane;
-        const uint32_t v = (L <= nlev) ? ((hist[L] + 63u) & ~63u) : 0u;
-        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane);
-        if (L <= nlev) lstart[L] = carry + incl - v;
+        const uint32_t v = (L <= nlev) ? hist[L] : 0u;
+        const uint32_t nch = (v + 63u) >> 6;
+        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane), cincl = (uint32_t)wave_incl_scan((int)nch, lane);
+        const uint32_t start = carry + incl - v, cb = ccarry + cincl - nch;
+        if (L <= nlev) {
+            lstart[L] = start;
+            for (uint32_t c = 0; c < nch; ++c)
+                if (cb + c < (uint32_t)A.chunk_cap) chunks[cb + c] = (start + 64u * c) | ((min(64u, v - 64u * c) - 1u) << 26);
+        }
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        ccarry += (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
     }
     // an overflowed group is left alone by the later phases (the step is re-run with larger tables)
-    const bool usable = !over && carry <= (uint32_t)A.sort_cap;
+    const bool usable = !over && ccarry <= (uint32_t)A.chunk_cap && carry <= (uint32_t)A.sort_cap;
     if (lane == 0) {
         lstart[nlev + 1] = carry;
-        A.grp_nchunks[g] = usable ? (int)(carry >> 6) : 0;
+        A.grp_nchunks[g] = usable ? (int)ccarry : 0;
         A.grp_nlev[g] = usable ? nlev : 0;
     }
 }
@@ -578,11 +587,14 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_levels16_kernel(EggPacke
 extern "C" __global__ void __launch_bounds__(64) egg_pk_levels64_kernel(EggPackedArgs A) { egg_pk_levels_body<64>(A); }
 
 // Phase 2b: counting sort of a group's pairs by level (one workgroup per group: the walk above is one wave, this
-// part has no dependencies and wants many loads in flight).  Indices become group-local; bit 31 marks a pair; the
-// padding behind every level is zeroed.
-extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_kernel(EggPackedArgs A) {
+// part has no dependencies and wants many loads in flight).  Indices become group-local; bit 31 marks a pair.
+// IN_LDS: the sorted list is assembled in LDS and written out in whole lines (a scatter straight to global memory
+// leaves every 64-byte line half a dozen partial writes apart in time: several times the bytes at the memory side).
+template <bool IN_LDS>
+__device__ __forceinline__ void egg_pk_sort_body(const EggPackedArgs &A) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *cursor = (uint32_t *)smem;  // [nlev + 2] next free slot of every level
+    uint32_t *sbuf = (uint32_t *)(smem + egg_align16((size_t)(A.lev_cap + 2) * 4));
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
     const int tid = threadIdx.x;
@@ -593,7 +605,9 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_kernel(EggPackedAr
     const uint32_t *lstart = A.lev_start + (size_t)g * (A.lev_cap + 2);
     for (int L = 1 + tid; L <= nlev + 1; L += 256) cursor[L] = lstart[L];
     __syncthreads();
+    const uint32_t total = cursor[nlev + 1];
     uint32_t *sorted = A.sorted + (size_t)g * A.sort_cap;
+    uint32_t *dst = IN_LDS ? sbuf : sorted;
     // a wave per tile, twelve entries per lane requested before the first is used: a sparse tile's whole stream in one
     // memory round trip
     const int lane = tid & 63;
@@ -614,27 +628,25 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_kernel(EggPackedAr
             for (int u = 0; u < 12; ++u)
                 if (e0 + 64 * u + lane < slen) {
                     const uint32_t pos = atomicAdd(&cursor[l[u]], 1u);
-                    sorted[pos] = 0x80000000u | ((rec[u] & 0x7FFFu) + base) | (rec[u] & 0x8000u) | ((((rec[u] >> 16) & 0x7FFFu) + base) << 16);
+                    dst[pos] = 0x80000000u | ((rec[u] & 0x7FFFu) + base) | (rec[u] & 0x8000u) | ((((rec[u] >> 16) & 0x7FFFu) + base) << 16);
                 }
         }
     }
-    __syncthreads();
-    // padding: from where a level's pairs end to where the next level starts (fewer than 64 words)
-    for (int L = 1 + tid; L <= nlev; L += 256) {
-        const uint32_t end = lstart[L + 1];
-        for (uint32_t x = cursor[L]; x < end; ++x) sorted[x] = 0u;
+    if (IN_LDS) {
+        __syncthreads();
+        for (uint32_t x = (uint32_t)tid; x < total; x += 256) sorted[x] = sbuf[x];
     }
 }
+extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_kernel(EggPackedArgs A) { egg_pk_sort_body<true>(A); }
+extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_direct_kernel(EggPackedArgs A) { egg_pk_sort_body<false>(A); }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 3: the pair projections (L:1514-1545, L:1632-1654), chunk after chunk: the 64 words [64 c, 64 c + 64) of
-// the group's sorted list are pairs of ONE level (or padding), so a wave-instruction projects up to 64 pairs.  The
-// work list is static, so the loads of the next chunks run ahead of the arithmetic: the entries three chunks
-// ahead, the (inverse mass, radius) records of both particles two chunks ahead; only the positions are read when
-// they are needed -- from LDS.
+// Phase 3: the pair projections (L:1514-1545, L:1632-1654), chunk after chunk: at most 64 pairs of ONE level per
+// wave-instruction.  The work list is static, so everything but the positions runs ahead of the arithmetic: the
+// chunk descriptors come by scalar loads, the entries are requested three chunks ahead, the (inverse mass, radius)
+// records of both particles two chunks ahead; the positions are read when they are needed -- from LDS.
 extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double2 *lpos = (double2 *)smem;
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
     const int lane = threadIdx.x;
@@ -642,15 +654,15 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
     if (nch <= 0) return;  // nothing to do: positions stay as they are
     const int4 gg = ((const int4 *)A.grp_geo)[g];
     const int p0 = __builtin_amdgcn_readfirstlane(gg.z), np = __builtin_amdgcn_readfirstlane(gg.w);
+    double2 *lpos = (double2 *)smem;
     double2 *gpos = (double2 *)A.pk_pos + p0;
     const double2 *gwr = (const double2 *)A.pk_wr + p0;
-    const uint32_t *sorted = A.sorted + (size_t)g * A.sort_cap + lane;
-    // Software pipeline over the static work list.  The ring of four stages is indexed with compile-time constants
-    // (the loop is unrolled by four), so nothing is copied and no load is waited for before its chunk is due.
-    uint32_t rec[4];
-    double2 wa[4], wb[4];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) rec[u] = (u < nch) ? sorted[64 * u] : 0u;
+    const uint32_t *sorted = A.sorted + (size_t)g * A.sort_cap;
+    const uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
+    // chunk descriptors are wave-uniform: read through the constant address space they arrive by scalar loads, beside
+    // the vector memory pipeline (written by the previous launch; the scalar cache starts every launch clean)
+    typedef const __attribute__((address_space(4))) uint32_t egg_const_u32;
+    egg_const_u32 *kchunks = (egg_const_u32 *)(uintptr_t)chunks;
     // the group's positions into LDS: eight loads in flight per lane (a load-wait-store loop pays one memory
     // round trip per 64 particles)
     for (int i0 = 0; i0 < np; i0 += 512) {
@@ -663,6 +675,23 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
         for (int u = 0; u < 8; ++u) lpos[min(i0 + 64 * u + lane, np - 1)] = v[u];
     }
     const double overlap = A.overlap_factor, compliance = A.collision_compliance, eps = A.eps;
+    auto load_desc = [&](int c) -> uint32_t { return kchunks[min(c, nch - 1)]; };
+    auto load_rec = [&](int c, uint32_t desc) -> uint32_t {  // the entries of chunk c; 0 for the lanes beyond it and the list
+        const uint32_t start = desc & 0x3FFFFFFu, cnt = (c < nch) ? (desc >> 26) + 1u : 0u;
+        // (unconditional load: the lanes beyond the chunk read the words behind it -- the list has 64 spare words -- and
+        // drop them; a load under a lane mask costs a branch per chunk)
+        const uint32_t w = sorted[start + (uint32_t)lane];
+        return ((uint32_t)lane < cnt) ? w : 0u;
+    };
+    // Software pipeline over the static work list: descriptor four chunks ahead (scalar), entries three, particle
+    // constants two.  The rings of four stages are indexed with compile-time constants (the loop is unrolled by four),
+    // so nothing is copied and no load is waited for before its chunk is due.
+    uint32_t dsc[4], rec[4];
+    double2 wa[4], wb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dsc[u] = load_desc(u);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) rec[u] = load_rec(u, dsc[u]);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         wa[u] = gwr[rec[u] & 0x7FFFu];
@@ -672,11 +701,12 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u;
-            rec[(u + 3) & 3] = sorted[64 * min(c + 3, nch - 1)];  // (past the end: the last chunk again, never used)
+            rec[(u + 3) & 3] = load_rec(c + 3, dsc[(u + 3) & 3]);
+            dsc[u] = load_desc(c + 4);
             wa[(u + 2) & 3] = gwr[rec[(u + 2) & 3] & 0x7FFFu];
             wb[(u + 2) & 3] = gwr[(rec[(u + 2) & 3] >> 16) & 0x7FFFu];
             const uint32_t r0 = rec[u];
-            if (c < nch && (r0 >> 31)) {
+            if (r0 >> 31) {
                 const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
                 double2 pa = lpos[ga], pb = lpos[gb];
                 project_pair<false>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },

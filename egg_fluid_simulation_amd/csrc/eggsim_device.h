@@ -194,6 +194,11 @@ static inline size_t egg_pk_levels_lds_bytes(int lev_cap, int group_particles, i
     return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 2) +
            egg_align16((size_t)(64 / wd) * EGG_PK_WINDOW * 4);
 }
+// the multi-run walk (egg_pk_levels_mr*): also a stamp word per particle; `threads` / wd sub-waves
+static inline size_t egg_pk_levels_mr_lds_bytes(int lev_cap, int group_particles, int wd, int threads) {
+    return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 2) +
+           egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(threads / wd) * EGG_PK_WINDOW * 4);
+}
 
 // the arguments of up to four launch classes sharing one launch (egg_step_kernel_multi*); unused slots have n_tiles = 0
 struct EggStepArgs4 {

@@ -46,6 +46,8 @@ extern "C" __global__ void egg_pk_lists_stale_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels8_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels16_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels64_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_levels_mr16_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_levels_mr32_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_exec_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_sort_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_sort_direct_kernel(EggPackedArgs A);
@@ -161,6 +163,7 @@ struct PackedClass {
     size_t meta_tile_geo = 0, meta_grp_geo = 0;  // offsets (ints) into System::pk_meta
     int max_group_particles = 0;
     int wd = 8;             // lanes per tile in the level walk
+    int levels_threads = 64; // workgroup of the level walk (the multi-run walk spreads a group's tiles over up to four waves)
     int lcap = 0, scap = 0;  // visit entries / stream words (entries + one header per particle) a tile may have
     int stage_cap = 0;       // partners per particle the list kernel's counting pass keeps in LDS
     int sort_cap = 0;        // words of a group's sorted list
@@ -277,6 +280,8 @@ struct egg_handle {
     int opt_force_single = 0;
     int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
     int opt_spin_sleep = -1;  // -1 auto
+    int opt_levels_wd = 0;    // developer override of the multi-run walk's sub-wave width (16 or 32; 0 = by tile size)
+    int opt_levels_mr = 1;    // packed pipeline: the level walk takes several runs per turn (0: one run per turn; A/B testing)
     int opt_packed = -1;      // packed pipeline: -1 automatic (large scenes), 0 never, 1 every eligible class
     int opt_group_particles = 1280;  // particles one wave of the packed executor keeps in LDS (16 B each: 8 such waves fill a CU's 160 KiB)
     int opt_force_global_state = 0;  // test hook: run every tile through the global-memory-state kernel  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
@@ -894,8 +899,15 @@ int retile(egg_handle *h, int which) {
                 t = t_end;
             }
             const int per_group = (lc.n_tiles + pc.n_groups - 1) / pc.n_groups;
-            pc.wd = per_group >= 8 ? 8 : 16;
-            pc.lds_levels = egg_pk_levels_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd);
+            if (h->opt_levels_mr) {
+                pc.wd = h->opt_levels_wd ? h->opt_levels_wd : (lc.nmax <= 256 ? 16 : 32);
+                pc.levels_threads = std::min(256, (max_tiles_in_group * pc.wd + 63) / 64 * 64);
+                pc.lds_levels = egg_pk_levels_mr_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd, pc.levels_threads);
+            } else {
+                pc.wd = per_group >= 8 ? 8 : 16;
+                pc.levels_threads = 64;
+                pc.lds_levels = egg_pk_levels_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd);
+            }
             const size_t sort_words = (size_t)max_tiles_in_group * (size_t)pc.scap + 64;
             pc.chunk_cap = (int)std::min<size_t>(sort_words / 64 + (size_t)s.pk_lev_cap + 8, (size_t)1 << 28);
             pc.lds_exec = (size_t)pc.max_group_particles * 16;
@@ -1215,10 +1227,11 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
             launch_all(stale ? EGG_PK_KIND_LISTS_STALE : EGG_PK_KIND_LISTS_FRESH,
                        [&](const PackedClass &) { return stale ? egg_pk_lists_stale_kernel : egg_pk_lists_fresh_kernel; }, tiles_of,
                        [](const PackedClass &pc) { return pc.threads_lists; }, [](const PackedClass &pc) { return pc.lds_lists; });
-            launch_all(EGG_PK_KIND_LEVELS, [](const PackedClass &pc) {
+            launch_all(EGG_PK_KIND_LEVELS, [&](const PackedClass &pc) {
+                           if (h->opt_levels_mr) return pc.wd == 16 ? egg_pk_levels_mr16_kernel : egg_pk_levels_mr32_kernel;
                            return pc.wd == 8 ? egg_pk_levels8_kernel : pc.wd == 16 ? egg_pk_levels16_kernel : egg_pk_levels64_kernel;
                        },
-                       groups_of, c64, [](const PackedClass &pc) { return pc.lds_levels; });
+                       groups_of, [](const PackedClass &pc) { return pc.levels_threads; }, [](const PackedClass &pc) { return pc.lds_levels; });
             launch_all(EGG_PK_KIND_SORT, [](const PackedClass &pc) { return pc.lds_sort ? egg_pk_sort_kernel : egg_pk_sort_direct_kernel; },
                        groups_of, c256,
                        [&](const PackedClass &pc) { return pc.lds_sort ? pc.lds_sort : egg_align16((size_t)(s.pk_lev_cap + 2) * 4); });
@@ -1725,7 +1738,8 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
             for (const void *f : {(const void *)egg_pk_lists_fresh_kernel, (const void *)egg_pk_lists_stale_kernel,
                                   (const void *)egg_pk_levels8_kernel, (const void *)egg_pk_levels16_kernel,
                                   (const void *)egg_pk_levels64_kernel, (const void *)egg_pk_exec_kernel,
-                                  (const void *)egg_pk_sort_kernel})
+                                  (const void *)egg_pk_sort_kernel, (const void *)egg_pk_levels_mr16_kernel,
+                                  (const void *)egg_pk_levels_mr32_kernel})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess) {
             h->lds_limit = want;
@@ -1734,6 +1748,8 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
     }
     (void)hipGetLastError();
     if (const char *e_pk = getenv("EGGSIM_PACKED")) h->opt_packed = atoi(e_pk);  // developer / test override of EGG_OPT_PACKED
+    if (const char *e_mr = getenv("EGGSIM_LEVELS_MR")) h->opt_levels_mr = atoi(e_mr) != 0;
+    if (const char *e_wd = getenv("EGGSIM_LEVELS_WD")) h->opt_levels_wd = atoi(e_wd) == 32 ? 32 : atoi(e_wd) == 16 ? 16 : 0;
     if (const char *e_gp = getenv("EGGSIM_GROUP_PARTICLES")) h->opt_group_particles = std::max(1, atoi(e_gp));
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];

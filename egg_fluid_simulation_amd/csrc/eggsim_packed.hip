@@ -586,6 +586,187 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_levels8_kernel(EggPacked
 extern "C" __global__ void __launch_bounds__(64) egg_pk_levels16_kernel(EggPackedArgs A) { egg_pk_levels_body<16>(A); }
 extern "C" __global__ void __launch_bounds__(64) egg_pk_levels64_kernel(EggPackedArgs A) { egg_pk_levels_body<64>(A); }
 
+// The same walk, several runs per turn.  A turn takes the next WD entries whatever selves they belong to; runs of
+// different selves may be levelled side by side when they touch no common particle, which is found out on the spot:
+// every entry stamps its two particles with the index of its run inside the turn (LDS minimum: the earliest run
+// wins), reads the stamps back, and a run that finds an earlier run's stamp on one of its particles ends the turn
+// in front of it (the first run never conflicts, so every turn makes progress).  The particles of consecutive selves
+// are rarely the same -- neighbours in index are not neighbours in space (the batches are Fibonacci spirals) -- so
+// a turn carries two to four runs, and the walk needs that many fewer turns.  Inside a turn each run is a segment
+// of the prefix-maximum scan.  One workgroup per group, one sub-wave per tile at a time.
+template <int WD>
+__device__ __forceinline__ void egg_pk_levels_mr_body(const EggPackedArgs &A) {
+    static_assert(WD == 16 || WD == 32, "segments are scanned inside rows of 16 lanes plus one cross-row step");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int g = blockIdx.x;
+    if (g >= A.n_groups) return;
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int4 gg = ((const int4 *)A.grp_geo)[g];
+    const int t0 = __builtin_amdgcn_readfirstlane(gg.x), t1 = __builtin_amdgcn_readfirstlane(gg.y);
+    const int p0 = __builtin_amdgcn_readfirstlane(gg.z), np = __builtin_amdgcn_readfirstlane(gg.w);
+    const int lev_cap = A.lev_cap;
+    constexpr int W = EGG_PK_WINDOW;
+    const int nsubs = nthreads / WD;
+    uint32_t *hist = (uint32_t *)smem;  // [lev_cap + 2] pairs per level
+    unsigned char *q8 = smem + egg_align16((size_t)(lev_cap + 2) * 4);
+    uint16_t *last = (uint16_t *)q8;  // [np] level of each particle's last pair
+    q8 += egg_align16((size_t)np * 2);
+    uint32_t *stamp = (uint32_t *)q8;  // [np] earliest run of the turn in progress that touches the particle
+    q8 += egg_align16((size_t)np * 4);
+    uint32_t *win_all = (uint32_t *)q8;
+    __shared__ int wave_max[16], wave_over[16];
+    for (int i = tid; i <= lev_cap + 1; i += nthreads) hist[i] = 0;
+    for (int i = tid; i < np; i += nthreads) {
+        last[i] = 0;
+        stamp[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const int subg = tid / WD, sl = tid % WD, sub = lane / WD;  // sub-wave in the workgroup / lane in it / sub-wave in the wave
+    uint32_t *win = win_all + subg * W;
+    int maxlev = 0;
+    bool over = false;
+    for (int ti = t0 + subg; ti < t1; ti += nsubs) {
+        const int base = ((const int4 *)A.tile_geo)[2 * ti].x - p0;
+        const int slen = A.tile_total[ti];
+        const uint32_t *stream = A.lists + (size_t)ti * A.scap;
+        uint16_t *lv = A.lvl + (size_t)ti * A.scap;
+        constexpr int PF = (W + WD) / WD;
+        uint32_t pf[PF];
+        int pf_base = 0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) pf[u] = stream[min(sl + WD * u, max(slen - 1, 0))];
+        int q = 0, wlen = 0, r = 0;
+        while (q + r < slen) {
+            if (r + WD > wlen && q + wlen < slen) {  // fewer than WD entries left in the window and more in the stream
+                q += r;
+                r = 0;
+                wlen = min(W, slen - q);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int pos = pf_base + sl + WD * u - q;
+                    if (pos >= 0 && pos < W) win[pos] = pf[u];
+                }
+                pf_base = q + W - WD;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) pf[u] = stream[min(pf_base + sl + WD * u, slen - 1)];
+            }
+            const int avail = min(wlen - r, WD);  // >= 1
+            const bool have = sl < avail;
+            const uint32_t rec = have ? win[r + sl] : 0u;
+            const int a = (int)(rec & 0x7FFFu), b = (int)((rec >> 16) & 0x7FFFu);
+            // run structure of the turn: a run starts where the self changes
+            const int a_prev = __builtin_amdgcn_update_dpp(-1, a, 0x111, 0xf, 0xf, false);  // row_shr:1
+            const int a_before = (WD == 32 && (sl & 15) == 0 && sl > 0) ? __shfl_up(a, 1, WD) : a_prev;
+            const bool head = have && (sl == 0 || a != a_before);
+            const unsigned long long heads64 = __ballot(head);
+            const uint32_t heads = (uint32_t)(heads64 >> (sub * WD)) & (WD == 32 ? 0xFFFFFFFFu : 0xFFFFu);
+            const uint32_t upto = heads & (0xFFFFFFFFu >> (31 - sl));          // heads at lanes <= sl
+            const int run_idx = __builtin_popcount(upto) - 1;
+            const int run_start = 31 - __builtin_clz(upto | 1u);
+            const int pos_in_run = sl - run_start;
+            // the earliest run of the turn to touch a particle leaves its index on it
+            if (have) {
+                atomicMin(&stamp[base + b], (uint32_t)run_idx);
+                atomicMin(&stamp[base + a], (uint32_t)run_idx);
+            }
+            const uint32_t sb = stamp[base + b], sa = stamp[base + a];
+            const int c_raw = (int)last[base + b];
+            const int xa = (int)last[base + a];
+            if (have) {  // the stamps are the next turn's again
+                stamp[base + b] = 0xFFFFFFFFu;
+                stamp[base + a] = 0xFFFFFFFFu;
+            }
+            const bool clash = have && (sb < (uint32_t)run_idx || sa < (uint32_t)run_idx);
+            const unsigned long long clash64 = __ballot(clash);
+            const uint32_t clashes = (uint32_t)(clash64 >> (sub * WD)) & (WD == 32 ? 0xFFFFFFFFu : 0xFFFFu);
+            // the turn ends in front of the first run that clashes with an earlier one
+            int m = avail;
+            if (clashes) {
+                const int f = __builtin_ctz(clashes);
+                m = 31 - __builtin_clz((heads & (0xFFFFFFFFu >> (31 - f))) | 1u);  // start of the run lane f is in
+            }
+            const bool valid = sl < m;
+            // segmented inclusive prefix maximum of (level of the partner's last pair - position in the run)
+            int v = valid ? c_raw - pos_in_run : EGG_NEG_LEVEL;
+            {
+                int t;
+                t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+                if (pos_in_run >= 1 && (sl & 15) >= 1) v = max(v, t);
+                t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+                if (pos_in_run >= 2 && (sl & 15) >= 2) v = max(v, t);
+                t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+                if (pos_in_run >= 4 && (sl & 15) >= 4) v = max(v, t);
+                t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+                if (pos_in_run >= 8 && (sl & 15) >= 8) v = max(v, t);
+            }
+            if (WD == 32) {  // the part of a run that lies in the previous row of 16: its maximum is in that row's last lane
+                const int carry = __shfl(v, 15, WD);
+                if (sl >= 16 && pos_in_run > (sl & 15)) v = max(v, carry);
+                // (lane 15 holds the maximum over its own run's lanes in row 0; a run crossing the row boundary is the
+                // run of lane 15, so the carry belongs to exactly the lanes whose run started before lane 16)
+            }
+            int l = pos_in_run + 1 + max(xa, v);
+            if (valid && l > lev_cap) {  // deeper than the level table: report what is needed, keep the tables in range
+                over = true;
+                maxlev = max(maxlev, l);
+                l = lev_cap;
+            }
+            if (valid) {
+                const bool run_ends = (sl == m - 1) || ((heads >> (sl + 1)) & 1u);
+                last[base + b] = (uint16_t)l;
+                lv[q + r + sl] = (uint16_t)l;
+                atomicAdd(&hist[l], 1u);
+                maxlev = max(maxlev, l);
+                if (run_ends) last[base + a] = (uint16_t)l;
+            }
+            r += m;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxlev = max(maxlev, __shfl_xor(maxlev, d, 64));
+    over = __any(over);
+    if (lane == 0) {
+        wave_max[tid >> 6] = maxlev;
+        wave_over[tid >> 6] = over ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    for (int w = 0; w < nthreads / 64; ++w) {
+        maxlev = max(maxlev, wave_max[w]);
+        over = over || wave_over[w];
+    }
+    if (over && lane == 0) {
+        atomicExch(&A.status->fail_levels, 1);
+        atomicMax(&A.status->max_level, maxlev);
+    }
+    const int nlev = min(maxlev, lev_cap);
+    uint32_t *lstart = A.lev_start + (size_t)g * (lev_cap + 2);
+    uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
+    uint32_t carry = 0, ccarry = 0;
+    for (int b0 = 1; b0 <= nlev; b0 += 64) {
+        const int L = b0 + lane;
+        const uint32_t v = (L <= nlev) ? hist[L] : 0u;
+        const uint32_t nch = (v + 63u) >> 6;
+        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane), cincl = (uint32_t)wave_incl_scan((int)nch, lane);
+        const uint32_t start = carry + incl - v, cb = ccarry + cincl - nch;
+        if (L <= nlev) {
+            lstart[L] = start;
+            for (uint32_t c = 0; c < nch; ++c)
+                if (cb + c < (uint32_t)A.chunk_cap) chunks[cb + c] = (start + 64u * c) | ((min(64u, v - 64u * c) - 1u) << 26);
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        ccarry += (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
+    }
+    const bool usable = !over && ccarry <= (uint32_t)A.chunk_cap && carry <= (uint32_t)A.sort_cap;
+    if (lane == 0) {
+        lstart[nlev + 1] = carry;
+        A.grp_nchunks[g] = usable ? (int)ccarry : 0;
+        A.grp_nlev[g] = usable ? nlev : 0;
+    }
+}
+extern "C" __global__ void __launch_bounds__(256) egg_pk_levels_mr16_kernel(EggPackedArgs A) { egg_pk_levels_mr_body<16>(A); }
+extern "C" __global__ void __launch_bounds__(256) egg_pk_levels_mr32_kernel(EggPackedArgs A) { egg_pk_levels_mr_body<32>(A); }
+
 // Phase 2b: counting sort of a group's pairs by level (one workgroup per group: the walk above is one wave, this
 // part has no dependencies and wants many loads in flight).  Indices become group-local; bit 31 marks a pair.
 // IN_LDS: the sorted list is assembled in LDS and written out in whole lines (a scatter straight to global memory

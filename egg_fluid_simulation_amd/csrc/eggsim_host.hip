@@ -840,12 +840,15 @@ int retile(egg_handle *h, int which) {
             pc.n_tiles = lc.n_tiles;
             pc.lcap = lc.lcap;
             pc.scap = lc.lcap;
-            pc.threads_lists = egg_step_threads(lc.nmax, 1);
-            // the counting pass keeps up to stage_cap partners per particle while that costs little LDS
-            for (pc.stage_cap = 16; pc.stage_cap > 0; pc.stage_cap -= 4) {
-                pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap);
-                if (pc.lds_lists <= 24 * 1024 || (size_t)pc.stage_cap * lc.nmax * 2 <= pc.lds_lists / 4) break;
-            }
+            pc.threads_lists = egg_step_threads(lc.nmax, 1);  // (capping it at 512 to fit a fourth dense tile per CU cost 50 %)
+            // the counting pass keeps up to stage_cap partners per particle in LDS as long as that does not cost a
+            // resident tile per CU (residency: LDS and the 32-wave limit)
+            auto tiles_per_cu = [&](int stage) {
+                const size_t lds = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, stage);
+                return std::min<size_t>(kLdsMax / std::max<size_t>(lds, 1), (size_t)2048 / (size_t)pc.threads_lists);
+            };
+            for (pc.stage_cap = 16; pc.stage_cap > 0; pc.stage_cap -= 4)
+                if (tiles_per_cu(pc.stage_cap) == tiles_per_cu(0)) break;
             pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap);
             if (pc.lds_lists > h->lds_limit) continue;
             const size_t meta_mark = s.pk_meta_host.size();
@@ -900,7 +903,7 @@ int retile(egg_handle *h, int which) {
             }
             const int per_group = (lc.n_tiles + pc.n_groups - 1) / pc.n_groups;
             if (h->opt_levels_mr) {
-                pc.wd = h->opt_levels_wd ? h->opt_levels_wd : (lc.nmax <= 256 ? 16 : 32);
+                pc.wd = h->opt_levels_wd ? h->opt_levels_wd : 16;  // (32 lanes per tile gained nothing on dense islands)
                 pc.levels_threads = std::min(256, (max_tiles_in_group * pc.wd + 63) / 64 * 64);
                 pc.lds_levels = egg_pk_levels_mr_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd, pc.levels_threads);
             } else {

@@ -284,7 +284,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
         const size_t n = (size_t)A.nmax, a = (size_t)A.amax, cc = (size_t)A.ccap;
         unsigned char *p = smem;
         t.pos = (double2 *)carve(p, n * 16);
-        t.wr = (double2 *)carve(p, n * 16);
+        t.wr = nullptr;  // (inverse mass, radius) stay in global memory: only the rare slow-pair test reads them per pair
         t.ckey_b = (uint32_t *)carve(p, 2 * n * 4);
         t.cell_b = (uint32_t *)carve(p, 2 * cc * 4);
         t.hkeys_b = (uint32_t *)carve(p, A.use_grid ? 0 : 2 * cc * 4);
@@ -328,7 +328,6 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     const uint32_t *g_ckey_prev = A.pk_ckey + (size_t)((A.substep + 1) & 1) * A.pk_stride + p0;
     for (int i = tid; i < n; i += nthreads) {
         t.pos[i] = ((const double2 *)A.pk_pos)[p0 + i];
-        t.wr[i] = ((const double2 *)A.pk_wr)[p0 + i];
         t.aslot[i] = A.pk_aslot[p0 + i];
         if (STALE) t.ckey(prev)[i] = g_ckey_prev[i];
     }
@@ -338,7 +337,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     // monotonic; NaN fails the comparisons).  Nearly always true; the per-pair test then drops out of the fill.
     bool mine_fast = A.collision_compliance <= 0x1p298;
     for (int i = tid; i < n; i += nthreads) {
-        const double2 w = t.wr[i];
+        const double2 w = ((const double2 *)A.pk_wr)[p0 + i];
         mine_fast = mine_fast && (w.x >= A.eps * 0.5) && (w.x <= 0x1p298) && (fabs(A.overlap_factor * w.y) <= 0x1p298);
     }
     const bool all_fast = __syncthreads_and(mine_fast) != 0;
@@ -407,9 +406,9 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
         for (int i = tid; i < n; i += nthreads) {
             const int cnt = (int)t.fill[i];
             uint32_t *dst = gstream + own_off[i];
-            const double2 wi = t.wr[i];
+            const double2 wi = all_fast ? make_double2(0.0, 0.0) : ((const double2 *)A.pk_wr)[p0 + i];
             auto emit = [&](int k, int j) {
-                const double2 wj = t.wr[j];
+                const double2 wj = ((const double2 *)A.pk_wr)[p0 + j];
                 const bool slow = pair_needs_reference(wi, wj, A.overlap_factor, A.collision_compliance, A.eps);
                 // a pair failing the mass guard (L:1601) is marked in `collided` but leaves n_collided alone
                 if (slow && wi.x + wj.x < A.eps) ++guarded;

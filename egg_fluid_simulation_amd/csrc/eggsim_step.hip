@@ -358,6 +358,10 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
         }
     }
     __syncthreads();
+    // can any pair of this tile fail the mass guard w_i + w_j < eps (L:1601)?  (NaN compares false there: not guarded)
+    bool tile_guard_mine = false;
+    for (int i = tid; i < n; i += nthreads) tile_guard_mine |= t.wr[i].x * 2.0 < A.eps;
+    const bool tile_guard = __syncthreads_or(tile_guard_mine) != 0;
     // Velocity and sub-step start position are private to a particle.  With one thread per
     // particle (n <= threads) they stay in that thread's registers for the whole step; only tiles
     // with more particles than threads keep them in LDS.
@@ -665,7 +669,7 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
                 for (int e = tid; e < total; e += nthreads) t.own_ent(cur)[e] = (uint16_t)t.own_pack[e];
             }
             if (tid == 0) {
-                t.sc[11] = 0;  // pairs of this pass that fail the mass guard (counted by the rank pass below)
+                atomicAdd(&A.status->visits[min(pass_seq, EGG_MAX_PASSES - 1)], (unsigned long long)total);
                 if (this_cut) atomicExch(&A.status->was_cut, 1);
             }
 
@@ -715,8 +719,6 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
                 // bit 15: this pair must take the reference path (position-independent part of the test)
                 const uint32_t slow = pair_needs_reference(t.wr[cself], t.wr[i], A.overlap_factor, A.collision_compliance, eps)
                                           ? 0x8000u : 0u;
-                // a pair failing the mass guard (L:1601) is marked in `collided` but leaves n_collided alone
-                if (slow && t.wr[cself].x + t.wr[i].x < eps) atomicAdd(&t.sc[11], 1);
                 t.own_pack[e] = (uint32_t)i | slow | (rank << 16);
                 if (t.pinv) {
                     const double2 ws = t.wr[cself], wo = t.wr[i];
@@ -736,8 +738,27 @@ __device__ __forceinline__ void egg_step_body(const Args &A, const int tile = (i
                 t.nlo[i] = (uint16_t)nl;
             }
             __syncthreads();
-            if (tid == 0)  // n_collided of this pass (L:1657): the visited pairs that passed the mass guard
-                atomicAdd(&A.status->visits[min(pass_seq, EGG_MAX_PASSES - 1)], (unsigned long long)(total - t.sc[11]));
+            // n_collided of this pass (L:1657) counts the visited pairs that passed the mass guard (L:1601): take the
+            // others off again.  There are none unless some inverse mass is below eps / 2 (tile_guard, found once per
+            // step when the tile is loaded), so the common case pays nothing here -- the hot variants of this kernel
+            // sit at their register caps, and a per-pair count inside the rank pass moved spill code into the pair
+            // scheduler's loop (+20 % time at four tiles per CU).
+            if (tile_guard) {
+                unsigned int mine = 0;
+                for (int e = tid; e < total; e += nthreads) {
+                    const uint32_t rec = t.own_pack[e];
+                    // (entries hold `other`; the self of entry e is found through the offsets)
+                    int lo = 0, hi = n - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if ((int)t.own_off(cur)[mid] <= e) lo = mid; else hi = mid - 1;
+                    }
+                    if (t.wr[lo].x + t.wr[rec & EGG_IDX].x < eps) ++mine;
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+                if (lane == 0 && mine) atomicAdd(&A.status->visits[min(pass_seq, EGG_MAX_PASSES - 1)], 0ull - (unsigned long long)mine);
+            }
 
             PROF(6)  // transpose
             // -------------------------------------- dataflow execution of the pair projections

@@ -280,6 +280,7 @@ struct egg_handle {
     int opt_force_single = 0;
     int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
     int opt_spin_sleep = -1;  // -1 auto
+    bool packed_auto = false;  // the automatic choice, made when the white tiles are formed
     int opt_levels_wd = 0;    // developer override of the multi-run walk's sub-wave width (16 or 32; 0 = by tile size)
     int opt_levels_mr = 1;    // packed pipeline: the level walk takes several runs per turn (0: one run per turn; A/B testing)
     int opt_packed = -1;      // packed pipeline: -1 automatic (large scenes), 0 never, 1 every eligible class
@@ -828,9 +829,17 @@ int retile(egg_handle *h, int which) {
     s.pk_chunk_words = 0;
     {
         // automatic: scenes large enough that the chip is full of tiles whatever the kernel (the fused kernel's
-        // latency per step is lower while every tile has a CU almost to itself); judged on the white particles so
+        // latency per step is lower while every tile has a CU almost to itself); judged on the white tiles so
         // that both types of a scene take the same path
-        const bool want = h->opt_packed > 0 || (h->opt_packed < 0 && h->sys[0].n >= 200000);
+        // Measured crossover on MI355X (ms per step, fused vs packed): separate 157-particle blobs 1536: 0.78 / 0.78,
+        // 2048: 1.06 / 1.04, 3072: 1.39 / 0.90; dense 628-particle islands 256: 1.60 / 2.72, 1024: 5.9 / 3.2 -- the packed
+        // pipeline has a latency floor per collision pass, the fused kernel's time grows with the tiles per CU.
+        if (which == 0) {
+            const int64_t cus = std::max(1, h->prop.multiProcessorCount);
+            const bool dense = !tiles.empty() && tiles.front().particles > 256;
+            h->packed_auto = (int64_t)tiles.size() >= (dense ? 2 : 6) * cus;
+        }
+        const bool want = h->opt_packed > 0 || (h->opt_packed < 0 && h->packed_auto);
         const bool allowed = want && !single && s.gens <= 2 && s.pk_allowed;
         for (size_t ci = 0; allowed && ci < s.classes.size(); ++ci) {
             LaunchClass &lc = s.classes[ci];

@@ -843,7 +843,7 @@ int retile(egg_handle *h, int which) {
         const bool allowed = want && !single && s.gens <= 2 && s.pk_allowed;
         for (size_t ci = 0; allowed && ci < s.classes.size(); ++ci) {
             LaunchClass &lc = s.classes[ci];
-            if (lc.global_state || lc.nmax > 8192) continue;
+            if (lc.nmax > 8192) continue;  // (a class whose FUSED kernel would keep its state in global memory may still fit: the list kernel's LDS need is checked below)
             PackedClass pc;
             pc.cls = (int)ci;
             pc.n_tiles = lc.n_tiles;
@@ -854,6 +854,7 @@ int retile(egg_handle *h, int which) {
             // resident tile per CU (residency: LDS and the 32-wave limit)
             auto tiles_per_cu = [&](int stage) {
                 const size_t lds = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, stage);
+                if (lds > h->lds_limit) return (size_t)0;  // (what a workgroup may have is a little less than the CU's 160 KiB)
                 return std::min<size_t>(kLdsMax / std::max<size_t>(lds, 1), (size_t)2048 / (size_t)pc.threads_lists);
             };
             for (pc.stage_cap = 16; pc.stage_cap > 0; pc.stage_cap -= 4)

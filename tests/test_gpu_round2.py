@@ -227,3 +227,114 @@ def test_state_changes_are_refused_while_a_step_is_in_flight(egg, oracle_mod):
     o.step(1 / 60, 2, 3)
     _same(h, o, "after the refused calls")
     assert h.list_ids() == [1, 2]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The packed pipeline (csrc/eggsim_packed.hip: one launch per phase, level-sorted pair execution) is chosen
+# automatically for large scenes only.  Here it is FORCED (EGG_OPT_PACKED = 1) on scenes the sequential oracle can
+# follow, so that every kernel of it is held to the oracle bit for bit: goldens, every (sub-steps, passes) shape it
+# supports, overlapping / coincident batches, moving targets with re-tiling every step, live config changes, adds and
+# removes, and the fused kernel stepping the same scene (both paths must give the same bits).
+
+def _packed(egg, **kw):
+    from egg_fluid_simulation_amd import _ffi
+    h = egg.SimulationHandler(**kw)
+    h.set_option(_ffi.OPT_PACKED, 1)
+    return h
+
+
+@pytest.mark.parametrize("name", ["cfg1_moving", "four_batches", "substeps_3_2", "substeps_2_1"])
+def test_packed_pipeline_matches_golden(egg, name):
+    from conftest import load_golden, replay_golden
+    g = load_golden(name)
+    h = _packed(egg)
+
+    def state(hh, w):
+        return np.array([hh.download(w, f) for f in ("x", "y", "vx", "vy")])
+
+    def check(step, tag, arr):
+        assert np.array_equal(arr, g["%s_step%d" % (tag, step)]), (name, step, tag)
+
+    replay_golden(g, h, state, check)
+    assert h.stats()["pair_solves"] == int(g["visits"].sum())
+    # one batch: the yolk budget binds -> that type runs the exact-budget fused tile, the white type the packed pipeline
+    assert h.stats()["packed"][WHITE] >= 1
+
+
+@pytest.mark.parametrize("S,C", [(1, 1), (1, 3), (2, 1), (2, 2), (2, 3), (3, 2), (4, 3)])
+def test_packed_pipeline_substep_and_pass_shapes(egg, oracle_mod, S, C):
+    """fresh passes, the stale first pass of every later sub-step (L:1905-1912), one pass per sub-step with two
+    sub-steps (two live hash generations); three or more generations fall back to the fused kernel"""
+    n = 14
+    xs = 100.0 + 95.0 * (np.arange(n) % 5)
+    ys = 100.0 + 95.0 * (np.arange(n) // 5)
+    h, o = _packed(egg), oracle_mod.Oracle()
+    ids = h.add_many(xs, ys, 50, 15)
+    for a, b in zip(xs, ys):
+        o.add(float(a), float(b), 50, 15)
+    for k in range(8):
+        dx, dy = 30.0 * np.cos(0.4 * k), 30.0 * np.sin(0.4 * k)
+        h.set_target_positions(ids, xs + dx, ys + dy)
+        for i, a, b in zip(ids, xs, ys):
+            o.set_target_position(int(i), float(a + dx), float(b + dy))
+        h.step(1 / 60, S, C)
+        o.step(1 / 60, S, C)
+        _same(h, o, (S, C, k))
+    assert h.stats()["packed"][WHITE] >= 1, h.stats()  # (the blobs merge into one 2198-particle island)
+
+
+def test_packed_pipeline_dense_and_sparse_islands_with_hand_made_chaos(egg, oracle_mod):
+    """coincident batches (dense islands, lists beyond LDS), separate blobs, a blob chasing a teleporting target through
+    the others (islands merge and split, claims fail and steps are re-run), a live config change, a remove and an add"""
+    from egg_fluid_simulation_amd.default_config import default_configs
+    rng = np.random.default_rng(11)
+    h, o = _packed(egg), oracle_mod.Oracle()
+    centers = [(300.0, 300.0)] * 4 + [(900.0 + 170.0 * (k % 4), 200.0 + 170.0 * (k // 4)) for k in range(12)]
+    ids = []
+    for x, y in centers:
+        ids.append(h.add(x, y, 50, 15))
+        assert o.add(x, y, 50, 15) == ids[-1]
+    tx, ty = 300.0, 300.0
+    for step in range(30):
+        if step % 7 == 3:
+            tx, ty = (float(v) for v in rng.uniform(200, 1400, 2))
+        h.set_target_position(ids[0], tx, ty)
+        o.set_target_position(ids[0], tx, ty)
+        if step == 10:
+            w, y = default_configs()
+            w.update(dict(damping=0.3, max_mass=3.0, collision_strength=0.9))
+            h.set_white_config(w)
+            o.set_config(WHITE, dict(oracle_mod.DEFAULT_WHITE, damping=0.3, max_mass=3.0, collision_strength=0.9))
+        if step == 15:
+            h.remove(ids[6])
+            o.remove(ids[6])
+        if step == 18:
+            assert h.add(1000.0, 900.0, 35, 9) == o.add(1000.0, 900.0, 35, 9)
+        S, C = [(2, 3), (2, 3), (1, 3), (2, 2)][step % 4]
+        h.step(1 / 60, S, C)
+        o.step(1 / 60, S, C)
+        if step % 5 == 4:
+            _same(h, o, step)
+    _same(h, o, "end")
+    assert h.stats()["packed"][WHITE] >= 1
+
+
+def test_packed_and_fused_paths_give_the_same_bits(egg):
+    from egg_fluid_simulation_amd import _ffi
+    n = 400
+    xs = 100.0 + 160.0 * (np.arange(n) % 20)
+    ys = 100.0 + 160.0 * (np.arange(n) // 20)
+    out = []
+    for packed in (0, 1):
+        h = egg.SimulationHandler()
+        h.set_option(_ffi.OPT_PACKED, packed)
+        ids = h.add_many(xs, ys, 50, 15)
+        for k in range(6):
+            h.set_target_positions(ids, xs + 6.0 * k, ys - 4.0 * k)
+            h.step(1 / 60, 2, 3)
+        st = h.stats()
+        assert (st["packed"][WHITE] >= 1) == bool(packed)
+        out.append([h.download(w, f) for w in (WHITE, YOLK) for f in ("x", "y", "vx", "vy")] + [st["pair_solves"]])
+    for a, b in zip(out[0][:-1], out[1][:-1]):
+        assert np.array_equal(a, b)
+    assert out[0][-1] == out[1][-1]

@@ -26,9 +26,10 @@ steps_per_sec is the lock-step rate of the whole job.  The reference Lua path ca
 (oracle/, single thread because the reference is single-threaded) on sites of the same workload.
 
 roofline: SURVEY.md 8d's byte model prices a step at 592 B per particle.  Large scenes run the PACKED pipeline
-(one launch per phase, csrc/eggsim_packed.hip): `kernel_ms` is then the sum of the average HIP-event durations of
-all launches that step the white particles (the yolk launches run beside them on their own stream), measured in
-a short profiling leg after the timed region; `dominant_kernel` names the launch kind with the largest share.
+(one launch per phase, csrc/eggsim_packed.hip): `kernel_ms` is then the HIP-event time of ALL launches that step the
+white particles in one step (events around the white stream's launch sequence, inside the timed region; the yolk
+launches run beside them on their own stream); a short profiling leg after the timed region puts events around
+every launch: `kernels` lists them, `dominant_kernel` names the kind with the largest share.
 Small scenes run the fused step kernel: one launch per step, timed inside the timed region.  `traffic` and
 `valu` are rocprofv3 counter measurements of the same workload committed under profiles/ (they cannot be taken
 from inside the process); they are attached only when the workload matches.
@@ -257,13 +258,18 @@ def main():
                "along the pair-dependency order, not by HBM bytes: see `traffic`, `valu` and DESIGN.md"
         if packed and per_kernel:
             white = [k for k in per_kernel if k["type"] == "white"]
-            kernel_ms = sum(k["ms_per_step"] for k in white)          # all launches stepping the white particles
+            # all launches stepping the white particles: HIP events around the white stream's launches of a step, inside
+            # the timed region (the per-launch events of the profiling leg add up to a little more: they fence the
+            # launches off from each other)
+            kernel_ms = kernel_ms_white
+            sum_of_launches = sum(k["ms_per_step"] for k in white)
             dom = max(white, key=lambda k: k["ms_per_step"])
             algo_bytes = ALGO_BYTES_PER_PARTICLE_STEP * n_white
             kernel_name = "packed pipeline, white particles: %d launches per step (%s)" % (
                 round(sum(k["launches_per_step"] for k in white)), ", ".join(sorted({k["kernel"] for k in white})))
             dominant = {"kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
-                        "share_of_kernel_ms": dom["ms_per_step"] / kernel_ms}
+                        "share_of_launch_time": dom["ms_per_step"] / sum_of_launches,
+                        "sum_of_white_launches_ms_per_step": sum_of_launches}
         else:
             kernel_ms = kernel_ms_white
             algo_bytes = ALGO_BYTES_PER_PARTICLE_STEP * ((n_white + n_yolk) if fused else n_white)

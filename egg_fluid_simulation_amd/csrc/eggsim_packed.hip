@@ -867,7 +867,12 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
     // constants two.  The rings of four stages are indexed with compile-time constants (the loop is unrolled by four),
     // so nothing is copied and no load is waited for before its chunk is due.
     uint32_t dsc[4], rec[4];
-    double2 wa[4], wb[4];
+    double2 wa[4], wb[4], pc[4];  // pc: what a pair's projection needs that does not depend on positions -- the refined
+                                  // reciprocal of its divisor and its minimum distance -- computed one chunk ahead, off
+                                  // the dependent chain of the chunk in progress
+    auto pair_constants = [&](double2 a, double2 b) {
+        return make_double2(egg_rcp_refined((a.x + b.x) + compliance), overlap * (a.y + b.y));
+    };
 #pragma unroll
     for (int u = 0; u < 4; ++u) dsc[u] = load_desc(u);
 #pragma unroll
@@ -877,6 +882,7 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
         wa[u] = gwr[rec[u] & 0x7FFFu];
         wb[u] = gwr[(rec[u] >> 16) & 0x7FFFu];
     }
+    pc[0] = pair_constants(wa[0], wb[0]);
     for (int c0 = 0; c0 < nch; c0 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -885,12 +891,13 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
             dsc[u] = load_desc(c + 4);
             wa[(u + 2) & 3] = gwr[rec[(u + 2) & 3] & 0x7FFFu];
             wb[(u + 2) & 3] = gwr[(rec[(u + 2) & 3] >> 16) & 0x7FFFu];
+            pc[(u + 1) & 3] = pair_constants(wa[(u + 1) & 3], wb[(u + 1) & 3]);
             const uint32_t r0 = rec[u];
             if (r0 >> 31) {
                 const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
                 double2 pa = lpos[ga], pb = lpos[gb];
-                project_pair<false>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
-                                    (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], wa[u], overlap, compliance, eps);
+                project_pair<true>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
+                                   (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], pc[u], overlap, compliance, eps);
                 lpos[ga] = pa;
                 lpos[gb] = pb;
             }

@@ -71,7 +71,8 @@ class EggStats(C.Structure):
                 ("last_step_kernel_ms", C.c_double), ("single_tile", C.c_int64 * 2),
                 ("kernel_ms", C.c_double * 2), ("kernel_ms_sum", C.c_double * 2), ("timed_steps", C.c_int64),
                 ("max_pass_visits", C.c_int64 * 2), ("budget", C.c_double * 2), ("fused_launch", C.c_int64),
-                ("packed", C.c_int64 * 2), ("pk_kernel_ms", (C.c_double * 9) * 2), ("pk_kernel_launches", (C.c_int64 * 9) * 2)]
+                ("packed", C.c_int64 * 2), ("pk_kernel_ms", (C.c_double * 9) * 2), ("pk_kernel_launches", (C.c_int64 * 9) * 2),
+                ("host_ms", C.c_double * 3)]
 
 
 PK_KINDS = ["egg_pk_begin_kernel", "egg_pk_mid_kernel", "egg_pk_lists_fresh_kernel", "egg_pk_lists_stale_kernel",

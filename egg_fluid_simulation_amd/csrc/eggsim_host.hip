@@ -214,6 +214,7 @@ struct System {  // one particle type
     DevBuf<unsigned char> d_meta;
     size_t meta_off_ty = 0, meta_off_fd = 0, meta_off_claim = 0, meta_off_tbegin = 0, meta_off_tatoms = 0;
     bool out_copied = false;  // stage_down holds this launch's boxes / travel
+    bool targets_moving = false;  // the caller moved targets before the most recent step
     bool eager_boxes = true;  // copy the atoms' boxes / travel back behind every step (the scene re-tiles every step: moving
                               // targets); a scene at rest fetches them only when a tiling needs them
     DevBuf<unsigned char> d_scratch;
@@ -518,8 +519,20 @@ int fetch_end_aabb(egg_handle *h, System &s);
 // tile to fill a wave.  Each atom's claim box is its padded box: the kernel verifies that
 // no particle leaves it, which proves that particles of different tiles never occupy
 // adjacent cells (claims of different islands are separated by >= 1 empty cell).
+// developer aid (EGGSIM_HOST_PROFILE=1): wall time of retile()'s sections, printed when the handle is destroyed
+static double g_retile_ms[8];
+struct RetileLap {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(int k) {
+        const auto n = std::chrono::steady_clock::now();
+        g_retile_ms[k] += std::chrono::duration<double, std::milli>(n - t).count();
+        t = n;
+    }
+};
+
 int retile(egg_handle *h, int which) {
     System &s = h->sys[which];
+    RetileLap lap;
     int rc = upload_atoms(h, which);
     if (rc != EGG_OK) return rc;
     const size_t na = s.atoms.size();
@@ -555,6 +568,7 @@ int retile(egg_handle *h, int which) {
         if (b.lo_x < -2000000000 || b.hi_x > 2000000000 || b.lo_y < -2000000000 || b.hi_y > 2000000000)
             return fail(h, EGG_ERR_UNSUPPORTED, "particle coordinates are not finite or exceed +-2e9 cells");
 
+    lap(0);
     std::vector<Box> claim(na);
     std::vector<int> comp(na);
     const bool single = s.single_tile || h->opt_force_single;
@@ -619,7 +633,8 @@ int retile(egg_handle *h, int which) {
             }
             claim[k] = Box{b.lo_x - side[1], b.lo_y - side[3], b.hi_x + side[0], b.hi_y + side[2]};
         }
-        // union-find over atoms; candidate pairs by a sweep over lo_x
+        lap(1);
+        // union-find over atoms
         std::vector<int> parent(na);
         std::iota(parent.begin(), parent.end(), 0);
         auto find = [&](int v) {
@@ -629,35 +644,101 @@ int retile(egg_handle *h, int which) {
             }
             return v;
         };
-        std::vector<int> order(na);
-        std::iota(order.begin(), order.end(), 0);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return claim[a].lo_x < claim[b].lo_x; });
-        for (size_t i = 0; i < na; ++i) {
-            const Box &A = claim[order[i]];
-            for (size_t j = i + 1; j < na; ++j) {
-                const Box &B = claim[order[j]];
-                if ((int64_t)B.lo_x > (int64_t)A.hi_x + 1) break;  // a full empty cell column between them
-                if ((int64_t)B.lo_y > (int64_t)A.hi_y + 1 || (int64_t)A.lo_y > (int64_t)B.hi_y + 1) continue;
-                int ra = find(order[i]), rb = find(order[j]);
-                if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+        auto touch = [&](int a, int b) {  // not separated by a full empty cell column or row
+            const Box &A = claim[(size_t)a], &B = claim[(size_t)b];
+            if ((int64_t)B.lo_x > (int64_t)A.hi_x + 1 || (int64_t)A.lo_x > (int64_t)B.hi_x + 1) return;
+            if ((int64_t)B.lo_y > (int64_t)A.hi_y + 1 || (int64_t)A.lo_y > (int64_t)B.hi_y + 1) return;
+            int ra = find(a), rb = find(b);
+            if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+        };
+        // Candidate pairs from a grid of square buckets as wide as an ordinary claim (+ the empty cell): two
+        // such claims that touch have their low corners in the same or in adjacent buckets.  The few claims wider
+        // than a bucket (a blob flying towards a far target) are tested against everything.
+        int64_t ext_sum = 0, ext_max = 0, min_x = std::numeric_limits<int64_t>::max(), min_y = min_x, max_x = -min_x, max_y = -min_x;
+        auto ext_of = [](const Box &c) { return std::max<int64_t>((int64_t)c.hi_x - c.lo_x, (int64_t)c.hi_y - c.lo_y) + 2; };
+        for (const Box &c : claim) {
+            const int64_t e = ext_of(c);
+            ext_sum += e;
+            ext_max = std::max(ext_max, e);
+            min_x = std::min<int64_t>(min_x, c.lo_x);
+            min_y = std::min<int64_t>(min_y, c.lo_y);
+            max_x = std::max<int64_t>(max_x, c.lo_x);
+            max_y = std::max<int64_t>(max_y, c.lo_y);
+        }
+        const int64_t ext_mean = ext_sum / (int64_t)na + 1;
+        const int64_t bucket = ext_max <= 4 * ext_mean ? ext_max : 2 * ext_mean;
+        const int64_t nbx = (max_x - min_x) / bucket + 1, nby = (max_y - min_y) / bucket + 1;
+        if (nbx * nby <= 8 * (int64_t)na + 1024) {
+            std::vector<int32_t> cell_of(na), start((size_t)(nbx * nby) + 1, 0), member(na), wide;
+            for (size_t k = 0; k < na; ++k) {
+                const Box &c = claim[k];
+                if (ext_of(c) > bucket) {
+                    cell_of[k] = -1;
+                    wide.push_back((int32_t)k);
+                    continue;
+                }
+                cell_of[k] = (int32_t)(((int64_t)c.lo_x - min_x) / bucket * nby + ((int64_t)c.lo_y - min_y) / bucket);
+                start[(size_t)cell_of[k] + 1]++;
             }
+            for (size_t c = 0; c < (size_t)(nbx * nby); ++c) start[c + 1] += start[c];
+            {
+                std::vector<int32_t> fill(start.begin(), start.end() - 1);
+                for (size_t k = 0; k < na; ++k)
+                    if (cell_of[k] >= 0) member[(size_t)fill[(size_t)cell_of[k]]++] = (int32_t)k;
+            }
+            for (size_t k = 0; k < na; ++k) {
+                const int32_t c = cell_of[k];
+                if (c < 0) continue;
+                const int64_t bx = c / nby, by = c % nby;
+                // own bucket (later members) and the four forward neighbours: every pair once
+                for (int32_t m = start[(size_t)c]; m < start[(size_t)c + 1]; ++m)
+                    if (member[(size_t)m] > (int32_t)k) touch((int)k, member[(size_t)m]);
+                const int64_t nb[4][2] = {{bx, by + 1}, {bx + 1, by - 1}, {bx + 1, by}, {bx + 1, by + 1}};
+                for (const auto &q : nb) {
+                    if (q[0] >= nbx || q[1] < 0 || q[1] >= nby) continue;
+                    const size_t c2 = (size_t)(q[0] * nby + q[1]);
+                    for (int32_t m = start[c2]; m < start[c2 + 1]; ++m) touch((int)k, member[(size_t)m]);
+                }
+            }
+            for (int32_t wk : wide)
+                for (size_t k = 0; k < na; ++k)
+                    if ((int32_t)k != wk) touch(wk, (int)k);
+        } else {
+            // atoms scattered over far more buckets than there are atoms: sweep over lo_x
+            std::vector<int> order(na);
+            std::iota(order.begin(), order.end(), 0);
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return claim[a].lo_x < claim[b].lo_x; });
+            for (size_t i = 0; i < na; ++i)
+                for (size_t j = i + 1; j < na; ++j) {
+                    if ((int64_t)claim[order[j]].lo_x > (int64_t)claim[order[i]].hi_x + 1) break;
+                    touch(order[i], order[j]);
+                }
         }
         for (size_t k = 0; k < na; ++k) comp[k] = find((int)k);
     }
 
-    // islands: atoms grouped by component, ascending atom index inside (keeps particle order)
-    std::vector<int> island_of(na, -1);
-    std::vector<std::vector<int32_t>> islands;
-    for (size_t k = 0; k < na; ++k) {
-        int r = comp[k];
-        if (island_of[r] < 0) {
-            island_of[r] = (int)islands.size();
-            islands.emplace_back();
+    lap(2);
+    // islands: atoms grouped by component (in the order of each component's first atom), ascending atom index
+    // inside (keeps particle order); flat arrays, this runs every step while blobs move
+    std::vector<int32_t> island_of(na, -1), isl_begin(1, 0), isl_atoms(na);
+    {
+        int32_t n_isl = 0;
+        std::vector<int32_t> size;
+        for (size_t k = 0; k < na; ++k) {
+            const int r = comp[k];
+            if (island_of[(size_t)r] < 0) {
+                island_of[(size_t)r] = n_isl++;
+                size.push_back(0);
+            }
+            size[(size_t)island_of[(size_t)r]]++;
         }
-        islands[(size_t)island_of[r]].push_back((int32_t)k);
+        isl_begin.resize((size_t)n_isl + 1);
+        for (int32_t i = 0; i < n_isl; ++i) isl_begin[(size_t)i + 1] = isl_begin[(size_t)i] + size[(size_t)i];
+        std::vector<int32_t> fill(isl_begin.begin(), isl_begin.end() - 1);
+        for (size_t k = 0; k < na; ++k) isl_atoms[(size_t)fill[(size_t)island_of[(size_t)comp[k]]]++] = (int32_t)k;
     }
-    struct TileTmp {
-        std::vector<int32_t> atoms;
+    struct TileTmp {  // atoms: isl_atoms[a_begin, a_end) -- islands that share a tile are neighbours in that array
+        int32_t a_begin = 0, a_end = 0;
         int64_t particles = 0;
         Box box{std::numeric_limits<int32_t>::max(), std::numeric_limits<int32_t>::max(),
                 std::numeric_limits<int32_t>::min(), std::numeric_limits<int32_t>::min()};
@@ -671,47 +752,40 @@ int retile(egg_handle *h, int which) {
     };
     auto extent = [](const Box &b) { return std::max<int64_t>((int64_t)b.hi_x - b.lo_x, (int64_t)b.hi_y - b.lo_y); };
     std::vector<TileTmp> tiles;
+    tiles.reserve(isl_begin.size());
     const int64_t target = single ? 0 : h->opt_tile_target;
-    for (auto &isl : islands) {
-        int64_t np = 0;
+    for (size_t i = 0; i + 1 < isl_begin.size(); ++i) {
         TileTmp one;
-        for (int32_t a : isl) {
-            np += s.atoms[(size_t)a].count;
+        one.a_begin = isl_begin[i];
+        one.a_end = isl_begin[i + 1];
+        for (int32_t k = one.a_begin; k < one.a_end; ++k) {
+            const int32_t a = isl_atoms[(size_t)k];
+            one.particles += s.atoms[(size_t)a].count;
             one.box = grow(one.box, claim[(size_t)a]);
         }
         // independent islands share a tile only while the joint claim box stays small enough for the dense cell
         // grid: a tile spanning the scene falls back to the hash table, which made such tiles (and with them
         // the whole launch) 7x slower
         auto grid_cells = [](const Box &b) { return ((int64_t)b.hi_x - b.lo_x + 4) * ((int64_t)b.hi_y - b.lo_y + 4); };
-        if (target > 0 && !tiles.empty() && tiles.back().particles + np <= target &&
+        if (target > 0 && !tiles.empty() && tiles.back().particles + one.particles <= target &&
             extent(grow(tiles.back().box, one.box)) <= 60000 && grid_cells(grow(tiles.back().box, one.box)) <= 2048) {
             // independent islands may share a tile (fills the wave's lanes in the pair executor)
             TileTmp &tt = tiles.back();
-            tt.atoms.insert(tt.atoms.end(), isl.begin(), isl.end());
-            tt.particles += np;
+            tt.a_end = one.a_end;
+            tt.particles += one.particles;
             tt.box = grow(tt.box, one.box);
         } else {
-            one.atoms = isl;
-            one.particles = np;
-            tiles.push_back(std::move(one));
+            tiles.push_back(one);
         }
     }
     for (auto &tt : tiles) {
-        std::sort(tt.atoms.begin(), tt.atoms.end());
+        std::sort(isl_atoms.begin() + tt.a_begin, isl_atoms.begin() + tt.a_end);
         if (tt.particles > kMaxTileParticles)
             return fail(h, EGG_ERR_UNSUPPORTED,
                         "%lld particles of one type interact in one island; the LDS tile kernel handles at most %d",
                         (long long)tt.particles, kMaxTileParticles);
-        int64_t ext_x = 0, ext_y = 0;
-        int32_t lx = std::numeric_limits<int32_t>::max(), ly = lx, hx = std::numeric_limits<int32_t>::min(), hy = hx;
-        for (int32_t a : tt.atoms) {
-            lx = std::min(lx, claim[(size_t)a].lo_x);
-            ly = std::min(ly, claim[(size_t)a].lo_y);
-            hx = std::max(hx, claim[(size_t)a].hi_x);
-            hy = std::max(hy, claim[(size_t)a].hi_y);
-        }
-        ext_x = (int64_t)hx - lx;
-        ext_y = (int64_t)hy - ly;
+        // (tt.box is the union of the tile's claims)
+        const int64_t ext_x = (int64_t)tt.box.hi_x - tt.box.lo_x, ext_y = (int64_t)tt.box.hi_y - tt.box.lo_y;
         if (ext_x > 65000 || ext_y > 65000)
             return fail(h, EGG_ERR_UNSUPPORTED, "a tile spans %lld x %lld cells; limit is 65000",
                         (long long)ext_x, (long long)ext_y);
@@ -720,10 +794,13 @@ int retile(egg_handle *h, int which) {
     std::stable_sort(tiles.begin(), tiles.end(),
                      [](const TileTmp &a, const TileTmp &b) { return a.particles > b.particles; });
 
+    s.tile_atoms.reserve(na);
+    s.tile_atom_begin.reserve(tiles.size() + 1);
     for (auto &tt : tiles) {
-        s.tile_atoms.insert(s.tile_atoms.end(), tt.atoms.begin(), tt.atoms.end());
+        s.tile_atoms.insert(s.tile_atoms.end(), isl_atoms.begin() + tt.a_begin, isl_atoms.begin() + tt.a_end);
         s.tile_atom_begin.push_back((int32_t)s.tile_atoms.size());
     }
+    lap(3);
     // launch classes: consecutive tiles whose particle count is within 2x
     size_t t0 = 0;
     size_t scratch_bytes = 0;
@@ -733,7 +810,7 @@ int retile(egg_handle *h, int which) {
         int amax = 0;
         int64_t max_cells = 0;
         while (t1 < tiles.size() && tiles[t1].particles * 2 > nmax) {
-            amax = std::max(amax, (int)tiles[t1].atoms.size());
+            amax = std::max(amax, (int)(tiles[t1].a_end - tiles[t1].a_begin));
             // dense grid the kernel lays over the tile's claim box (see eggsim_step.hip, load tile)
             const Box &bx = tiles[t1].box;
             max_cells = std::max(max_cells, ((int64_t)bx.hi_x - bx.lo_x + 4) * ((int64_t)bx.hi_y - bx.lo_y + 4));
@@ -820,6 +897,7 @@ int retile(egg_handle *h, int which) {
         t0 = t1;
     }
 
+    lap(4);
     // ---- packed pipeline (eggsim_packed.hip): which classes take it, their packed ranges and groups
     s.pk.clear();
     s.pk_meta_host.clear();
@@ -950,6 +1028,7 @@ int retile(egg_handle *h, int which) {
                 const int32_t rec[4] = {c.lo_x, c.lo_y, c.hi_x, c.hi_y};
                 s.pk_meta_host.insert(s.pk_meta_host.end(), rec, rec + 4);
             }
+            lap(5);
             const size_t np = (size_t)s.pk_n, nt = (size_t)s.pk_tiles, ng = (size_t)s.pk_groups;
             HIP_TRY(h, s.pk_meta.reserve(s.pk_meta_host.size() + 4, false, s.stream));
             HIP_TRY(h, s.pk_src.reserve(np, false, s.stream));
@@ -971,12 +1050,14 @@ int retile(egg_handle *h, int which) {
     }
 
     HIP_TRY(h, s.d_scratch.reserve(scratch_bytes + 16, false, s.stream));
+    lap(6);
     s.h_claim = claim;
     s.meta_dirty = true;
     s.tiling_dirty = false;
     h->stats.retiles++;
     h->stats.n_tiles[which] = (int64_t)tiles.size();
     h->stats.max_tile_particles[which] = tiles.empty() ? 0 : tiles.front().particles;
+    lap(7);
     return EGG_OK;
 }
 
@@ -1377,36 +1458,43 @@ int launch_fused(egg_handle *h, const Env *env, int S, int C) {
     return EGG_OK;
 }
 
-// atoms, targets and tiles (with the claims of the upcoming step) up to date on the host side
-int prepare_tiles(egg_handle *h) {
-    for (int w = 0; w < 2; ++w) {
-        System &s = h->sys[w];
-            int rc = upload_atoms(h, w);
-            if (rc != EGG_OK) return rc;
-            if (s.claims_stale && !s.tiling_dirty) {
-                // a moved target only matters when some blob is now farther from its target than its
-                // slack + what the margin absorbs; cheap test on the host copy of the boxes
-                if (!s.aabb_valid) {
-                    s.tiling_dirty = true;
-                } else {
-                    const double cell = cell_size_of(s.cfg);
-                    for (size_t k = 0; k < s.atoms.size() && !s.tiling_dirty; ++k) {
-                        const Box &b = s.aabb[k];
-                        const Batch &B = h->batches[(size_t)s.atoms[k].batch];
-                        const double cx = 0.5 * ((double)b.lo_x + b.hi_x + 1.0) * cell;
-                        const double cy = 0.5 * ((double)b.lo_y + b.hi_y + 1.0) * cell;
-                        const double dist = std::hypot(B.target_x - cx, B.target_y - cy);
-                        const double reach = 0.5 * cell * std::max(b.hi_x - b.lo_x, b.hi_y - b.lo_y) + 2 * cell * s.margin;
-                        if (!(dist <= reach + 64.0)) s.tiling_dirty = true;
-                    }
-                }
-            }
-            s.claims_stale = false;
-            if (s.tiling_dirty) {
-                rc = retile(h, w);
-                if (rc != EGG_OK) return rc;
+// atoms, targets and tiles (with the claims of the upcoming step) of one type up to date on the host side
+int prepare_type(egg_handle *h, int w) {
+    System &s = h->sys[w];
+    int rc = upload_atoms(h, w);
+    if (rc != EGG_OK) return rc;
+    if (s.claims_stale && !s.tiling_dirty) {
+        // a moved target only matters when some blob is now farther from its target than its
+        // slack + what the margin absorbs; cheap test on the host copy of the boxes
+        if (!s.aabb_valid) {
+            s.tiling_dirty = true;
+        } else {
+            const double cell = cell_size_of(s.cfg);
+            for (size_t k = 0; k < s.atoms.size() && !s.tiling_dirty; ++k) {
+                const Box &b = s.aabb[k];
+                const Batch &B = h->batches[(size_t)s.atoms[k].batch];
+                const double cx = 0.5 * ((double)b.lo_x + b.hi_x + 1.0) * cell;
+                const double cy = 0.5 * ((double)b.lo_y + b.hi_y + 1.0) * cell;
+                const double dist = std::hypot(B.target_x - cx, B.target_y - cy);
+                const double reach = 0.5 * cell * std::max(b.hi_x - b.lo_x, b.hi_y - b.lo_y) + 2 * cell * s.margin;
+                if (!(dist <= reach + 64.0)) s.tiling_dirty = true;
             }
         }
+    }
+    s.targets_moving = s.claims_stale;
+    s.claims_stale = false;
+    if (s.tiling_dirty) {
+        rc = retile(h, w);
+        if (rc != EGG_OK) return rc;
+    }
+    return EGG_OK;
+}
+
+int prepare_tiles(egg_handle *h) {
+    for (int w = 0; w < 2; ++w) {
+        int rc = prepare_type(h, w);
+        if (rc != EGG_OK) return rc;
+    }
     return EGG_OK;
 }
 
@@ -1468,19 +1556,47 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
     for (int attempt = 0;; ++attempt) {
         if (attempt > 24) return fail(h, EGG_ERR_INTERNAL, "step did not validate after %d attempts", attempt);
         if (!(phase == kEnd && attempt == 0)) {  // kEnd: the first attempt is already in flight
-            int rc = prepare_tiles(h);
+            auto now = [] { return std::chrono::steady_clock::now(); };
+            auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+            auto t0 = now();
+            int rc = prepare_type(h, 0);
             if (rc != EGG_OK) return rc;
-            h->stats.fused_launch = can_fuse(h) ? 1 : 0;
-            if (h->stats.fused_launch) {
-                rc = launch_fused(h, env, S, C);
+            bool white_packed = false;
+            for (const LaunchClass &lc : h->sys[0].classes) white_packed |= lc.packed >= 0;
+            if (white_packed) {
+                // the packed pipeline never shares a launch with the other type: the white launches go out now and
+                // run while the host clusters the yolk atoms (white first: it is the critical path)
+                h->stats.host_ms[0] += ms_since(t0);
+                t0 = now();
+                h->stats.fused_launch = 0;
+                rc = launch_type(h, 0, env[0], S, C);
+                if (rc != EGG_OK) return rc;
+                h->stats.host_ms[1] += ms_since(t0);
+                t0 = now();
+                rc = prepare_type(h, 1);
+                if (rc != EGG_OK) return rc;
+                h->stats.host_ms[0] += ms_since(t0);
+                t0 = now();
+                rc = launch_type(h, 1, env[1], S, C);
                 if (rc != EGG_OK) return rc;
             } else {
-                // white first: with at most a few tiles per CU it is the critical path
-                for (int w = 0; w < 2; ++w) {
-                    rc = launch_type(h, w, env[w], S, C);
+                rc = prepare_type(h, 1);
+                if (rc != EGG_OK) return rc;
+                h->stats.host_ms[0] += ms_since(t0);
+                t0 = now();
+                h->stats.fused_launch = can_fuse(h) ? 1 : 0;
+                if (h->stats.fused_launch) {
+                    rc = launch_fused(h, env, S, C);
                     if (rc != EGG_OK) return rc;
+                } else {
+                    // white first: with at most a few tiles per CU it is the critical path
+                    for (int w = 0; w < 2; ++w) {
+                        rc = launch_type(h, w, env[w], S, C);
+                        if (rc != EGG_OK) return rc;
+                    }
                 }
             }
+            h->stats.host_ms[1] += ms_since(t0);
             if (phase == kBegin) return EGG_OK;
         }
         bool redo = false;
@@ -1488,7 +1604,9 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
         for (int w = 0; w < 2; ++w) {
             System &s = h->sys[w];
             if (s.n == 0 || s.classes.empty()) continue;
+            const auto t_wait = std::chrono::steady_clock::now();
             HIP_TRY(h, wait_step(s.wait_stream ? s.wait_stream : s.stream));
+            h->stats.host_ms[2] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
             if (h->opt_timing) {
                 float t = 0;
                 const System &ts = h->sys[s.timing_from];
@@ -1617,7 +1735,8 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                 }
             }
             h->stats.single_tile[w] = s.single_tile;
-            s.eager_boxes = s.tiling_dirty || s.claims_stale;  // the next step re-tiles: so will the one after, probably
+            // the next step re-tiles, or targets are being moved step by step: the next tiling will want the boxes
+            s.eager_boxes = s.tiling_dirty || s.claims_stale || s.targets_moving;
         }
         h->stats.last_step_kernel_ms = ms;
         for (int w = 0; w < 2; ++w) {
@@ -1793,6 +1912,11 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
 
 void egg_destroy(egg_handle *h) {
     if (!h) return;
+    if (const char *e = getenv("EGGSIM_HOST_PROFILE"); e && atoi(e) && h->stats.retiles > 0) {
+        fprintf(stderr, "eggsim retile ms per call (%lld calls):", (long long)h->stats.retiles);
+        for (double v : g_retile_ms) fprintf(stderr, " %.4f", v / (double)h->stats.retiles);
+        fprintf(stderr, "\n");
+    }
     (void)hipSetDevice(h->device);
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];

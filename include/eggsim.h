@@ -219,6 +219,9 @@ typedef struct {
      * option was set: [type][kind], kind as in EGG_PK_KIND_* below */
     double pk_kernel_ms[2][EGG_PK_N_KINDS];
     int64_t pk_kernel_launches[2][EGG_PK_N_KINDS];
+    /* host wall time of _step's phases, summed since creation: [0] tiles and claims (re-clustering, packed plan), [1] uploads
+     * and kernel launches, [2] waiting for the status block */
+    double host_ms[3];
 } egg_stats;
 int egg_get_stats(egg_handle *h, egg_stats *out);
 

@@ -21,5 +21,7 @@ run(50, 0)
 s0 = h.stats(); t0 = time.perf_counter()
 run(300, 50)
 dt = time.perf_counter() - t0; s1 = h.stats()
+print("yolk kernel %.3f ms" % (s1["kernel_ms_sum"][1] / max(1, s1["timed_steps"])))
+print("host ms/step: prepare %.3f launch %.3f wait %.3f" % tuple((s1["host_ms"][i] - s0["host_ms"][i]) / 300 for i in range(3)))
 print("%d batches, targets moving %.1f px/step: %.1f steps/s, %.3f ms/step, white kernel %.3f ms, retiles %d, redo %d of 300 steps" % (
     nb, speed, 300 / dt, 1e3 * dt / 300, s1["kernel_ms_sum"][0] / max(1, s1["timed_steps"]), s1["retiles"] - s0["retiles"], s1["redo_steps"] - s0["redo_steps"]))

@@ -338,3 +338,28 @@ def test_packed_and_fused_paths_give_the_same_bits(egg):
     for a, b in zip(out[0][:-1], out[1][:-1]):
         assert np.array_equal(a, b)
     assert out[0][-1] == out[1][-1]
+
+
+def test_one_flying_blob_among_resting_ones(egg, oracle_mod):
+    """A blob sent across a field of resting blobs: its swept claim is many times wider than the others' (the host's
+    bucket grid treats it apart, eggsim_host.hip retile) and it merges with whatever it crosses on the way."""
+    xs, ys = _grid_xy(6)
+    h = egg.SimulationHandler()
+    o = oracle_mod.Oracle()
+    ids = h.add_many(xs, ys, 50, 15)
+    for x, y in zip(xs, ys):
+        o.add(float(x), float(y), 50, 15)
+    flyer = h.add(-700.0, 420.0, 50, 15)
+    assert o.add(-700.0, 420.0, 50, 15) == flyer
+    widest = 1
+    for step in range(24):
+        if step == 2:
+            for s in (h, o):
+                s.set_target_position(flyer, 1900.0, 470.0)
+        h.update(1 / 60)
+        o.update(1 / 60)
+        widest = max(widest, h.stats()["max_tile_particles"][WHITE] // N_W)
+    _same(h, o, "flyer")
+    assert h.get_position(flyer)[0] > 300.0  # it is inside the field (or beyond)
+    assert widest >= 2  # ... and shared a tile with the blobs it crossed
+    assert ids.size == 36

@@ -75,6 +75,19 @@ class EggStats(C.Structure):
                 ("host_ms", C.c_double * 3)]
 
 
+class EggRenderConfig(C.Structure):  # egg_render_config
+    _fields_ = [("color", C.c_float * 4), ("outline_color", C.c_float * 4), ("outline_thickness", C.c_double),
+                ("highlight_strength", C.c_double), ("shadow_strength", C.c_double), ("texture_scale", C.c_double),
+                ("motion_blur", C.c_double)]
+
+
+class EggRenderParams(C.Structure):  # egg_render_params
+    _fields_ = [("screen_w", C.c_int32), ("screen_h", C.c_int32), ("origin_x", C.c_double), ("origin_y", C.c_double),
+                ("interpolation_alpha", C.c_double), ("threshold", C.c_double), ("smoothness", C.c_double),
+                ("use_instancing", C.c_int32), ("canvas_w", C.c_int32 * 2), ("canvas_h", C.c_int32 * 2),
+                ("clear", C.c_float * 4)]
+
+
 PK_KINDS = ["egg_pk_begin_kernel", "egg_pk_mid_kernel", "egg_pk_lists_fresh_kernel", "egg_pk_lists_stale_kernel",
             "egg_pk_levels_kernel", "egg_pk_sort_kernel", "egg_pk_exec_kernel", "egg_pk_end_kernel", "egg_pk_reduce_kernel"]
 
@@ -118,6 +131,17 @@ _SIGNATURES = {
     "egg_get_stats": (C.c_int, [C.c_void_p, C.POINTER(EggStats)]),
     "egg_get_environment": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(EggEnvironment)]),
     "egg_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "egg_default_render_config": (C.c_int, [C.c_int, C.POINTER(EggRenderConfig)]),
+    "egg_set_render_config": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(EggRenderConfig)]),
+    "egg_get_render_config": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(EggRenderConfig)]),
+    "egg_set_render_flags": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "egg_set_add_color": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "egg_set_color": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "egg_default_render_params": (C.c_int, [C.POINTER(EggRenderParams)]),
+    "egg_render": (C.c_int, [C.c_void_p, C.POINTER(EggRenderParams), C.c_void_p]),
+    "egg_render_canvas": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "egg_render_particle_texture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
 }
 
 EXPORTED_SYMBOLS = sorted(_SIGNATURES)

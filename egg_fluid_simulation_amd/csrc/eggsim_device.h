@@ -200,6 +200,44 @@ static inline size_t egg_pk_levels_mr_lds_bytes(int lev_cap, int group_particles
            egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(threads / wd) * EGG_PK_WINDOW * 4);
 }
 
+// ---- headless renderer (eggsim_render.hip) ----
+#define EGG_RENDER_TILE 16    // canvas tile edge in px: one workgroup of 256 threads per tile
+#define EGG_RENDER_STAGE 128  // particles a tile stages in LDS at a time
+struct EggRenderArgs {  // pass 1 of one type: particles -> canvas (_update_canvases, L:1995-2113)
+    const double *x, *y, *last_x, *last_y, *vx, *vy, *radius;
+    const int32_t *atom_offset;  // first particle of every atom (= batch), ascending
+    const float4 *atom_color;    // the batch's particle colour (L:1110-1129)
+    int32_t n, n_atoms;
+    float t, tx, ty;             // interpolation alpha; translation world -> canvas px
+    float texture_scale, motion_blur;
+    int32_t premultiply;         // the non-instanced draw loop's setColor(r a, g a, b a, a) (L:2035-2041)
+    int32_t cw, ch, tiles_x, tiles_y;
+    uint32_t *tile_count, *tile_start, *tile_cursor;  // [tiles], [tiles + 1], [tiles]
+    uint32_t *entries;           // the tiles' particle lists
+    uint32_t *totals;            // [0] all list entries, [1] the longest list
+    const float *texture;        // tsize x tsize density texture
+    int32_t tsize;
+    float4 *canvas;              // ch x cw
+};
+// dynamic LDS of egg_render_splat_kernel: bordered texture, staged instances + colours, the tile's list (padded to 2^k)
+static inline size_t egg_render_splat_lds_bytes(int tsize, size_t padded_list) {
+    return egg_align16((size_t)(tsize + 2) * (tsize + 2) * 4) + (size_t)EGG_RENDER_STAGE * (32 + 16) + padded_list * 4;
+}
+struct EggCompositeLayer {  // pass 2 of one type (_draw_canvases, L:2117-2175)
+    const float4 *canvas;
+    int32_t w, h;
+    float x0, y0;  // the canvas's top-left corner on the screen
+    float4 color, outline_color;
+    float outline_thickness, highlight_strength, shadow_strength;
+};
+struct EggCompositeArgs {
+    float4 *screen;
+    int32_t screen_w, screen_h, n_layers;
+    float threshold, smoothness;
+    int32_t use_particle_color, use_lighting;
+    EggCompositeLayer layer[2];
+};
+
 // the arguments of up to four launch classes sharing one launch (egg_step_kernel_multi*); unused slots have n_tiles = 0
 struct EggStepArgs4 {
     EggStepArgs a[4];

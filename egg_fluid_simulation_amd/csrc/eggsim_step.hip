@@ -1210,24 +1210,59 @@ extern "C" __global__ void egg_env_bounds_kernel(const double *x, const double *
 }
 
 // Block b adds up array b (x, y, last_x, last_y) in particle order, like the reference's loops (L:1700-1701,
-// L:1803-1804): floating-point addition does not associate, so the sum is serial; the wave only stages 64
-// values at a time (one coalesced load) and every lane adds them in order.  out[b] = the sum.
-extern "C" __global__ void egg_env_sums_kernel(const double *a0, const double *a1, const double *a2, const double *a3, int n,
-                                                 double *out) {
+// L:1803-1804): floating-point addition does not associate, so the sum is serial.  One wave: every lane holds one
+// value of a 64-value row, the rows are added in order through constant-lane readlanes (two readlanes and one
+// dependent v_add_f64 per value; a counted loop with a lane index in an SGPR cost six dependent instructions,
+// ~90 cycles, per value).  Three blocks of four rows rotate without register copies, so the loads of the block
+// after next are in flight while a block is added.  out[b] = the sum.
+namespace {
+constexpr int kSumRows = 4;  // rows of 64 values per block
+__device__ __forceinline__ void sums_load(const double *a, int n, int base, int lane, double (&r)[kSumRows]) {
+#pragma unroll
+    for (int d = 0; d < kSumRows; ++d) {
+        // (unconditional, index clamped: rows past the end are never added, and a load inside a branch would make
+        // every wait a wait for ALL loads in flight)
+        r[d] = a[min(base + d * 64 + lane, n - 1)];
+    }
+}
+__device__ __forceinline__ double sums_add(double s, int n, int base, const double (&r)[kSumRows]) {
+#pragma unroll
+    for (int d = 0; d < kSumRows; ++d) {
+        const int m = n - (base + d * 64);  // values of this row
+        const int lo = (int)(__double_as_longlong(r[d]) & 0xFFFFFFFFll), hi = (int)(__double_as_longlong(r[d]) >> 32);
+        if (m >= 64) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                const unsigned int l = (unsigned int)__builtin_amdgcn_readlane(lo, k), u = (unsigned int)__builtin_amdgcn_readlane(hi, k);
+                s = s + __longlong_as_double((long long)(((unsigned long long)u << 32) | l));
+            }
+        } else {
+            for (int k = 0; k < m; ++k) {
+                const unsigned int l = (unsigned int)__builtin_amdgcn_readlane(lo, k), u = (unsigned int)__builtin_amdgcn_readlane(hi, k);
+                s = s + __longlong_as_double((long long)(((unsigned long long)u << 32) | l));
+            }
+        }
+    }
+    return s;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(64) egg_env_sums_kernel(const double *a0, const double *a1, const double *a2,
+                                                                      const double *a3, int n, double *out) {
     const double *a = blockIdx.x == 0 ? a0 : blockIdx.x == 1 ? a1 : blockIdx.x == 2 ? a2 : a3;
+    constexpr int kBlock = 64 * kSumRows;
     const int lane = threadIdx.x;
     double s = 0.0;
-    double v = (lane < n) ? a[lane] : 0.0;
-    for (int base = 0; base < n; base += 64) {
-        const double cur = v;
-        const int nxt = base + 64 + lane;
-        v = (nxt < n) ? a[nxt] : 0.0;  // next chunk travels while this one is added
-        const int m = min(64, n - base);
-        const int lo = (int)(__double_as_longlong(cur) & 0xFFFFFFFFll), hi = (int)(__double_as_longlong(cur) >> 32);
-        for (int k = 0; k < m; ++k) {
-            const unsigned int l = (unsigned int)__builtin_amdgcn_readlane(lo, k), u = (unsigned int)__builtin_amdgcn_readlane(hi, k);
-            s = s + __longlong_as_double((long long)(((unsigned long long)u << 32) | l));
-        }
+    double A[kSumRows], B[kSumRows], C[kSumRows];
+    sums_load(a, n, 0, lane, A);
+    sums_load(a, n, kBlock, lane, B);
+    for (int base = 0; base < n; base += 3 * kBlock) {
+        sums_load(a, n, base + 2 * kBlock, lane, C);
+        s = sums_add(s, n, base, A);
+        sums_load(a, n, base + 3 * kBlock, lane, A);
+        s = sums_add(s, n, base + kBlock, B);
+        sums_load(a, n, base + 4 * kBlock, lane, B);
+        s = sums_add(s, n, base + 2 * kBlock, C);
     }
     if (lane == 0) out[blockIdx.x] = s;
 }

@@ -8,9 +8,10 @@
 --- Surface kept from the reference (same names, argument order, defaults, warnings, errors):
 ---   SimulationHandler(white_config, yolk_config), :add, :remove, :update, :set_target_position,
 ---   :get_target_position, :get_position, :set_white_config/:set_yolk_config, :get_*_config,
----   :list_ids, :get_n_particles.  Rendering (:draw, colors) is outside the device path: :draw is
----   a stub, :get_instance_data() returns the reference's instanced-draw record
----   (x, y, last_x, last_y, vx, vy, radius) for a host renderer.
+---   :list_ids, :get_n_particles, :set_white_color, :set_yolk_color.  In a LOVE host :draw stays with the reference's
+---   own shaders: :get_instance_data() returns the instanced-draw record (x, y, last_x, last_y, vx, vy, radius) and
+---   :get_environment() what sizes and places the canvases.  Without a window, :render_to_image() runs the same
+---   passes as HIP kernels (include/eggsim.h, "headless renderer") into a float32 RGBA buffer.
 
 local prefix = "egg_fluid_simulation"
 require(string.gsub(prefix .. "/math", "[/\\]", "."))
@@ -42,6 +43,26 @@ int egg_download_particles(egg_handle *h, int which, int field, double *dst, int
 typedef struct { double min_x, min_y, max_x, max_y, centroid_x, centroid_y, max_radius, max_velocity,
                  last_centroid_x, last_centroid_y; } egg_environment;
 int egg_get_environment(egg_handle *h, int which, egg_environment *out);
+typedef struct {
+    float color[4], outline_color[4];
+    double outline_thickness;
+    double highlight_strength, shadow_strength;
+    double texture_scale, motion_blur;
+} egg_render_config;
+int egg_set_render_config(egg_handle *h, int which, const egg_render_config *cfg);
+int egg_set_add_color(egg_handle *h, int64_t id, int which, double r, double g, double b, double a);
+int egg_set_color(egg_handle *h, int64_t id, int which, double r, double g, double b, double a);
+typedef struct {
+    int32_t screen_w, screen_h;
+    double origin_x, origin_y;
+    double interpolation_alpha;
+    double threshold, smoothness;
+    int32_t use_instancing;
+    int32_t canvas_w[2], canvas_h[2];
+    float clear[4];
+} egg_render_params;
+int egg_default_render_params(egg_render_params *p);
+int egg_render(egg_handle *h, const egg_render_params *p, float *rgba);
 ]]
 
 local lib = ffi.load(os.getenv("EGGSIM_LIB") or "eggsim")
@@ -188,8 +209,57 @@ function SimulationHandler:add(x, y, white_radius, yolk_radius, white_color, yol
     self:_check(lib.egg_add(self._h, x, y, white_radius or NaN, yolk_radius or NaN,
         white_n_particles and math.ceil(white_n_particles) or EGG_DEFAULT_COUNT,
         yolk_n_particles and math.ceil(yolk_n_particles) or EGG_DEFAULT_COUNT, id))
-    self._batch_colors[tonumber(id[0])] = { white_color, yolk_color }
-    return tonumber(id[0])
+    local batch_id = tonumber(id[0])
+    -- a batch created without a colour shares the config's colour table (simulation_handler.lua:49-50)
+    self._batch_colors[batch_id] = { white_color or self._white_config.color, yolk_color or self._yolk_config.color }
+    if white_color ~= nil then lib.egg_set_add_color(self._h, batch_id, 0, white_color[1], white_color[2], white_color[3], white_color[4]) end
+    if yolk_color ~= nil then lib.egg_set_add_color(self._h, batch_id, 1, yolk_color[1], yolk_color[2], yolk_color[3], yolk_color[4]) end
+    return batch_id
+end
+
+--- the render keys of a config table as egg_render_config (simulation_handler_default_config.lua:22-36)
+function SimulationHandler:_c_render_config(white_or_yolk)
+    local cfg = white_or_yolk and self._white_config or self._yolk_config
+    local c = ffi.new("egg_render_config")
+    for i = 1, 4 do
+        c.color[i - 1] = cfg.color[i]
+        c.outline_color[i - 1] = cfg.outline_color[i]
+    end
+    c.outline_thickness, c.highlight_strength, c.shadow_strength = cfg.outline_thickness, cfg.highlight_strength, cfg.shadow_strength
+    c.texture_scale, c.motion_blur = cfg.texture_scale, cfg.motion_blur
+    return c
+end
+
+--- set_white_color / set_yolk_color (simulation_handler.lua:328-398): in place, like the reference
+function SimulationHandler:_set_color(scope, which, batch_id, r, g, b, a)
+    if a == nil then a = 1 end
+    log.assert(batch_id, "number", r, "number", g, "number", b, "number", a, "number")
+    if r > 1 or r < 0 or g > 1 or g < 0 or b > 1 or b < 0 or a > 1 or a < 0 then
+        log.warning("In SimulationHandler.", scope, ": color component is outside of [0, 1]")
+    end
+    local colors = self._batch_colors[batch_id]
+    if colors == nil then
+        log.warning("In SimulationHandler.", scope, ": no batch with id `", batch_id, "`")
+        return
+    end
+    local color = colors[which + 1]
+    color[1], color[2], color[3], color[4] = math.clamp(r, 0, 1), math.clamp(g, 0, 1), math.clamp(b, 0, 1), math.clamp(a, 0, 1)
+    lib.egg_set_color(self._h, batch_id, which, color[1], color[2], color[3], color[4])
+end
+function SimulationHandler:set_white_color(batch_id, r, g, b, a) self:_set_color("set_white_color", 0, batch_id, r, g, b, a) end
+function SimulationHandler:set_yolk_color(batch_id, r, g, b, a) self:_set_color("set_egg_yolk_color", 1, batch_id, r, g, b, a) end
+
+--- :draw() without a window: both passes of the reference's draw path as HIP kernels (include/eggsim.h) into a
+--- float32 RGBA buffer of width x height; world px = screen px + origin.  Returns the buffer (row-major).
+function SimulationHandler:render_to_image(width, height, origin_x, origin_y)
+    local p = ffi.new("egg_render_params[1]")
+    lib.egg_default_render_params(p)
+    p[0].screen_w, p[0].screen_h = width, height
+    p[0].origin_x, p[0].origin_y = origin_x or 0, origin_y or 0
+    for which = 0, 1 do self:_check(lib.egg_set_render_config(self._h, which, self:_c_render_config(which == 0))) end
+    local image = ffi.new("float[?]", width * height * 4)
+    self:_check(lib.egg_render(self._h, p, image))
+    return image
 end
 
 function SimulationHandler:remove(batch_id)
@@ -285,8 +355,8 @@ function SimulationHandler:get_environment(white_or_yolk)
 end
 
 function SimulationHandler:draw()
-    -- rendering is outside the device path; feed :get_instance_data() and :get_environment() to the reference's
-    -- shaders and canvas code
+    -- in a LOVE host: feed :get_instance_data() and :get_environment() to the reference's shaders and canvas code
+    -- (simulation_handler.lua:1995-2175); without a window use :render_to_image()
 end
 
 return SimulationHandler

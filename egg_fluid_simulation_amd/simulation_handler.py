@@ -99,12 +99,18 @@ class SimulationHandler:
         self._mass_distribution_variance = 4
         self._max_collision_fraction = 0.05
         self._batch_colors = {}
+        # render constants (L:444-449)
+        self._thresholding_threshold = 0.3
+        self._thresholding_smoothness = 0.01
+        self._use_particle_color_flag = False
+        self._use_lighting_flag = True
         h = C.c_void_p()
         rc = self._lib.egg_create(C.byref(self._c_config(True)), C.byref(self._c_config(False)), int(device),
                                   C.byref(h))
         if rc != _ffi.EGG_OK:
             raise EggError("[ERROR] In SimulationHandler.new: " + self._lib.egg_last_error(None).decode())
         self._h = h
+        self._send_render_config()
 
     def __del__(self):
         self.close()
@@ -164,15 +170,56 @@ class SimulationHandler:
         c.eps = 1e-8
         return c
 
+    _RENDER_DEFAULTS = dict(outline_thickness=1.0, highlight_strength=0.0, shadow_strength=0.0, texture_scale=12.0,
+                            motion_blur=0.0003)
+
+    def _send_render_config(self):
+        # this object's config tables are the authority for the render keys (colour tables may be shared with batches,
+        # L:49-50); the library gets a copy whenever they may have changed
+        for which in range(2):
+            self._check(self._lib.egg_set_render_config(self._h, which, C.byref(self._c_render_config(which == 0))))
+
+    def _c_render_config(self, white_or_yolk):
+        """the render keys of a config table (simulation_handler_default_config.lua:22-36) as egg_render_config"""
+        cfg = self._white_config if white_or_yolk else self._yolk_config
+        c = _ffi.EggRenderConfig()
+        c.color[:] = [float(v) for v in cfg.get("color", [1, 1, 1, 1])]
+        c.outline_color[:] = [float(v) for v in cfg.get("outline_color", [1, 1, 1, 1])]
+        for k, d in self._RENDER_DEFAULTS.items():
+            setattr(c, k, float(cfg.get(k, d)))
+        return c
+
+    # the handler's private render switches (L:448-449): particles take their batch's colour at `add` only while
+    # _use_particle_color is set (L:978-990)
+    @property
+    def _use_particle_color(self):
+        return self._use_particle_color_flag
+
+    @_use_particle_color.setter
+    def _use_particle_color(self, flag):
+        self._use_particle_color_flag = bool(flag)
+        self._check(self._lib.egg_set_render_flags(self._h, int(self._use_particle_color_flag), int(self._use_lighting_flag)))
+
+    @property
+    def _use_lighting(self):
+        return self._use_lighting_flag
+
+    @_use_lighting.setter
+    def _use_lighting(self, flag):
+        self._use_lighting_flag = bool(flag)
+        self._check(self._lib.egg_set_render_flags(self._h, int(self._use_particle_color_flag), int(self._use_lighting_flag)))
+
     def set_white_config(self, config):  # L:226-229
         _assert_types(config, "table")
         self._load_config(copy.deepcopy(config), True)
         self._check(self._lib.egg_set_config(self._h, _ffi.WHITE, C.byref(self._c_config(True))))
+        self._send_render_config()
 
     def set_yolk_config(self, config):  # L:233-236
         _assert_types(config, "table")
         self._load_config(copy.deepcopy(config), False)
         self._check(self._lib.egg_set_config(self._h, _ffi.YOLK, C.byref(self._c_config(False))))
+        self._send_render_config()
 
     def get_white_config(self):  # L:240-242
         return copy.deepcopy(self._white_config)
@@ -196,6 +243,7 @@ class SimulationHandler:
     def add(self, x, y, white_radius=None, yolk_radius=None, white_color=None, yolk_color=None,
             white_n_particles=None, yolk_n_particles=None):  # L:27-135
         _assert_types(x, "number", y, "number")
+        given = (white_color is not None, yolk_color is not None)
         white_color = white_color if white_color is not None else self._white_config.get("color", [1, 1, 1, 1])
         yolk_color = yolk_color if yolk_color is not None else self._yolk_config.get("color", [1, 1, 1, 1])
         for v in (white_radius, yolk_radius, white_n_particles, yolk_n_particles):
@@ -228,8 +276,12 @@ class SimulationHandler:
                                _ffi.DEFAULT_COUNT if yolk_n_particles is None else int(math.ceil(yolk_n_particles)),
                                C.byref(out))
         self._check(rc)
-        self._batch_colors[out.value] = ([min(max(c, 0), 1) for c in white_color[:4]],
-                                         [min(max(c, 0), 1) for c in yolk_color[:4]])
+        # L:49-50, L:124-129: a batch created without a colour shares the CONFIG's colour table (set_*_color on it then
+        # changes config.color too); the device library is told which tables are the batch's own
+        self._batch_colors[out.value] = [white_color, yolk_color]
+        for which, color in enumerate((white_color, yolk_color)):
+            if given[which]:
+                self._lib.egg_set_add_color(self._h, out.value, which, *[float(c) for c in color[:4]])
         return out.value
 
     def add_many(self, xs, ys, white_radius=None, yolk_radius=None, white_n_particles=None,
@@ -284,9 +336,45 @@ class SimulationHandler:
         if rc == _ffi.EGG_OK:
             self._batch_colors.pop(int(batch_id), None)
 
-    def draw(self):  # L:159-162
-        raise NotImplementedError(
-            "rendering is outside the device path; use download_instance_data() to feed a renderer")
+    def draw(self, screen_size=(800, 600), origin=(0.0, 0.0), interpolation_alpha=None, clear=(0.0, 0.0, 0.0, 0.0),
+             canvas_sizes=None, use_instancing=True):  # L:159-162
+        """`draw()` without a window: _update_canvases + _draw_canvases (L:1995-2175) as HIP kernels into a float32
+        RGBA image of screen_size = (width, height); world px = screen px + origin.  Returns an (H, W, 4) array.
+        canvas_sizes = [(w, h) white, (w, h) yolk] overrides the sizes resize_canvas_maybe would pick (L:1935-1975)."""
+        p = _ffi.EggRenderParams()
+        self._check(self._lib.egg_default_render_params(C.byref(p)))
+        p.screen_w, p.screen_h = int(screen_size[0]), int(screen_size[1])
+        p.origin_x, p.origin_y = float(origin[0]), float(origin[1])
+        if interpolation_alpha is not None:
+            p.interpolation_alpha = float(interpolation_alpha)
+        p.threshold = float(self._thresholding_threshold)
+        p.smoothness = float(self._thresholding_smoothness)
+        p.use_instancing = int(bool(use_instancing))
+        if canvas_sizes is not None:
+            for which in range(2):
+                p.canvas_w[which], p.canvas_h[which] = int(canvas_sizes[which][0]), int(canvas_sizes[which][1])
+        p.clear[:] = [float(c) for c in clear]
+        self._send_render_config()
+        image = np.empty((p.screen_h, p.screen_w, 4), dtype=np.float32)
+        self._check(self._lib.egg_render(self._h, C.byref(p), image.ctypes.data_as(C.c_void_p)))
+        return image
+
+    def render_canvas(self, which):
+        """the density canvas of `which` as the last draw() left it: ((h, w, 4) float32 array, (x0, y0) in world px)"""
+        w, h, x0, y0 = C.c_int32(), C.c_int32(), C.c_double(), C.c_double()
+        self._check(self._lib.egg_render_canvas(self._h, int(which), None, 0, C.byref(w), C.byref(h), C.byref(x0), C.byref(y0)))
+        canvas = np.empty((h.value, w.value, 4), dtype=np.float32)
+        self._check(self._lib.egg_render_canvas(self._h, int(which), canvas.ctypes.data_as(C.c_void_p), w.value * h.value,
+                                                None, None, None, None))
+        return canvas, (x0.value, y0.value)
+
+    def particle_texture(self):
+        """alpha of the particle density texture (L:620-682) the splat pass samples"""
+        n = C.c_int32()
+        self._check(self._lib.egg_render_particle_texture(self._h, None, 0, C.byref(n)))
+        tex = np.empty((n.value, n.value), dtype=np.float32)
+        self._check(self._lib.egg_render_particle_texture(self._h, tex.ctypes.data_as(C.c_void_p), tex.size, None))
+        return tex
 
     # ------------------------------------------------------------------ update
     def update(self, delta, step_delta=None, n_substeps=None, n_collision_steps=None):  # L:168-222
@@ -389,9 +477,14 @@ class SimulationHandler:
         if int(batch_id) not in self._batch_colors:
             warnings.warn("In SimulationHandler.%s: no batch with id `%s`" % (scope, batch_id), EggWarning)
             return
-        colors = list(self._batch_colors[int(batch_id)])
-        colors[which] = rgba
-        self._batch_colors[int(batch_id)] = tuple(colors)
+        # in place (L:349-350, L:386-387): a batch created without a colour shares the config's table
+        table = self._batch_colors[int(batch_id)][which]
+        if isinstance(table, list):
+            table[:] = rgba
+        else:
+            self._batch_colors[int(batch_id)][which] = rgba
+        self._lib.egg_set_color(self._h, int(batch_id), int(which), *[float(c) for c in rgba])  # its particles (L:1110-1129)
+        self._send_render_config()
 
     def set_white_color(self, batch_id, r, g, b, a=None, *outline):  # L:365-394
         self._set_color("set_white_color", 0, batch_id, r, g, b, a)

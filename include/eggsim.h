@@ -190,6 +190,54 @@ typedef struct {
 } egg_environment;
 int egg_get_environment(egg_handle *h, int which, egg_environment *out);
 
+/* ---- headless renderer: SimulationHandler:draw() (L:158-161) into a float32 RGBA image ----
+ * The reference draws through LOVE / OpenGL: _update_canvases (L:1995-2113, simulation_handler_instanced_draw.glsl over
+ * the texture of simulation_handler_particle_texture.glsl) splats every particle into one canvas per type, _draw_canvases
+ * (L:2117-2175, simulation_handler_outline.glsl, simulation_handler_lighting.glsl) composites them.  These entry points run
+ * the same passes as HIP kernels, for image-level regression without a window: float32 canvases sampled at pixel centres,
+ * no MSAA, instances blended in particle order (what GL guarantees).  Colours are straight rgba in [0, 1]. */
+typedef struct {
+    float color[4], outline_color[4];  /* config.color / config.outline_color (default_config.lua:22-23, 54-55) */
+    double outline_thickness;          /* px; 0 skips the outline pass AND its setColor (L:2137-2142) */
+    double highlight_strength, shadow_strength;
+    double texture_scale, motion_blur;
+} egg_render_config;
+int egg_default_render_config(int which, egg_render_config *cfg);
+/* the render keys of set_white_config / set_yolk_config (L:226-236): the config gets a NEW colour table, batches created
+ * without a colour keep the old one (L:1307-1311) */
+int egg_set_render_config(egg_handle *h, int which, const egg_render_config *cfg);
+int egg_get_render_config(const egg_handle *h, int which, egg_render_config *cfg);
+/* the handler's hidden constants _use_particle_color, _use_lighting (L:448-449).  With use_particle_color == 0 (default)
+ * particles are created white (L:985-990) whatever the batch colour is. */
+int egg_set_render_flags(egg_handle *h, int32_t use_particle_color, int32_t use_lighting);
+/* the white_color / yolk_color argument of add (L:22-23): the batch gets its own colour table; its particles take the
+ * colour only when use_particle_color is set (L:978-990).  Call right after egg_add. */
+int egg_set_add_color(egg_handle *h, int64_t id, int which, double r, double g, double b, double a);
+/* set_white_color / set_yolk_color (L:328-398): components are clamped to [0, 1]; the batch's particles take the colour
+ * (L:1110-1129).  A batch created without a colour argument shares the CONFIG's colour table (L:49-50), so the call
+ * also changes config.color -- the colour _draw_canvases tints the whole type with; that aliasing is the reference's.
+ * Unknown id: EGG_WARN_UNKNOWN_ID. */
+int egg_set_color(egg_handle *h, int64_t id, int which, double r, double g, double b, double a);
+typedef struct {
+    int32_t screen_w, screen_h;      /* render target; world px = screen px + origin (love.graphics.translate) */
+    double origin_x, origin_y;
+    double interpolation_alpha;      /* NaN: the handle's (egg_update, L:216) */
+    double threshold, smoothness;    /* _thresholding_threshold / _smoothness (L:444-445) */
+    int32_t use_instancing;          /* 1: instanced_draw.glsl; 0: the draw loop L:2009-2052 (colour premultiplied by its alpha) */
+    int32_t canvas_w[2], canvas_h[2];/* 0: from the environment's bounds (L:1945-1954), growing only over the calls */
+    float clear[4];                  /* what the screen holds before draw() */
+} egg_render_params;
+int egg_default_render_params(egg_render_params *p);
+/* draw(): clears the screen image to p->clear, runs both passes, copies screen_w * screen_h * 4 floats (row-major, RGBA)
+ * into rgba (may be NULL: the image stays on the device).  Nothing is drawn before the first _step or while one of the
+ * types has no particles (the reference has no canvas then: L:1997-1999, L:2118). */
+int egg_render(egg_handle *h, const egg_render_params *p, float *rgba);
+/* the density canvas of `which` as the last egg_render left it: *w x *h RGBA floats, its top-left corner in world px */
+int egg_render_canvas(egg_handle *h, int which, float *rgba, int64_t cap_pixels, int32_t *w, int32_t *hgt, double *x0,
+                      double *y0);
+/* the particle density texture (L:620-682): *size x *size alpha values (all four channels of the texture hold them) */
+int egg_render_particle_texture(egg_handle *h, float *alpha, int64_t cap, int32_t *size);
+
 /* kernels of the packed pipeline (csrc/eggsim_packed.hip), for egg_stats.pk_kernel_ms */
 enum {
     EGG_PK_KIND_BEGIN = 0, EGG_PK_KIND_MID, EGG_PK_KIND_LISTS_FRESH, EGG_PK_KIND_LISTS_STALE, EGG_PK_KIND_LEVELS,

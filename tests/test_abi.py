@@ -161,7 +161,7 @@ def test_lua_binding_declares_the_header_prototypes():
         assert name in header, name
         assert params == header[name], (name, params, header[name])
     # and the two structs it passes by pointer have the header's field order
-    for struct in ("egg_config", "egg_environment"):
+    for struct in ("egg_config", "egg_environment", "egg_render_config", "egg_render_params"):
         def fields(text):
             body = re.search(r"typedef struct\s*\{([^}]*)\}\s*" + struct + r"\s*;", re.sub(r"/\*.*?\*/", " ", text, flags=re.S), flags=re.S).group(1)
             return re.findall(r"[a-z_]+(?=\s*[,;])", body)

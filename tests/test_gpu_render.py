@@ -237,3 +237,25 @@ def test_config2_sized_scene_renders_every_blob(egg):
     gx, gy = int(round(0.5 * (xs[0] + xs[1]) - lo)), int(round(0.5 * (ys[0] + ys[side]) - (ys.min() - 120.0)))
     assert image[gy, gx, 3] == 0 and image[0, 0, 3] == 0 and image[cy[0], gx, 3] > 0
     assert np.array_equal(image, h.draw((size, size), origin=(lo, ys.min() - 120.0)))
+
+
+def test_device_matches_the_committed_image(egg):
+    """tests/golden/render_small.npz (oracle/gen_golden_render.py): the device steps the generator's scene itself and
+    must draw the committed image bit for bit -- no model run in between"""
+    import os
+    import warnings
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "render_small.npz"))
+    h = egg.SimulationHandler()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", egg.EggWarning)  # "only 14 white / 6 yolk particles will be created" (L:114-120)
+        h.add(100.0, 100.0, 20.0, 8.0, white_n_particles=14, yolk_n_particles=6)
+        b = h.add(130.0, 96.0, 20.0, 8.0, white_n_particles=14, yolk_n_particles=6)
+    h.set_target_position(b, 300.0, 160.0)
+    for _ in range(5):
+        h.step(1 / 60, 2, 3)
+    for w in (WHITE, YOLK):
+        assert np.array_equal(h.download(w, "x"), g["s%d_x" % w]) and np.array_equal(h.download(w, "vy"), g["s%d_vy" % w])
+    image = h.draw(tuple(int(v) for v in g["screen"]), tuple(g["origin"]), interpolation_alpha=float(g["alpha"]))
+    assert np.array_equal(image, g["image"])
+    assert [h.render_canvas(w)[0].shape[:2] for w in (WHITE, YOLK)] == [tuple(s) for s in g["canvas_shapes"]]

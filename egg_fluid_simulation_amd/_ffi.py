@@ -72,7 +72,7 @@ class EggStats(C.Structure):
                 ("kernel_ms", C.c_double * 2), ("kernel_ms_sum", C.c_double * 2), ("timed_steps", C.c_int64),
                 ("max_pass_visits", C.c_int64 * 2), ("budget", C.c_double * 2), ("fused_launch", C.c_int64),
                 ("packed", C.c_int64 * 2), ("pk_kernel_ms", (C.c_double * 9) * 2), ("pk_kernel_launches", (C.c_int64 * 9) * 2),
-                ("host_ms", C.c_double * 3)]
+                ("host_ms", C.c_double * 3), ("max_levels", C.c_int64 * 2)]
 
 
 class EggRenderConfig(C.Structure):  # egg_render_config

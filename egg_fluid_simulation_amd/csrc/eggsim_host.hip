@@ -1722,6 +1722,7 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                 most = std::max(most, (int64_t)st.visits[p]);
             }
             h->stats.max_pass_visits[w] = most;
+            h->stats.max_levels[w] = s.pk.empty() ? 0 : st.max_level;
             h->stats.budget[w] = env[w].budget;
             h->stats.follow_solves += s.n * S;
             s.aabb_on_device = true;  // d_atom_aabb now holds end-of-step cells

@@ -549,10 +549,10 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) maxlev = max(maxlev, __shfl_xor(maxlev, d, 64));
     over = __any(over);
-    if (over && lane == 0) {
-        atomicExch(&A.status->fail_levels, 1);
+    if (over && lane == 0) atomicExch(&A.status->fail_levels, 1);
+    // the deepest chain of the step (egg_stats.max_levels); most groups see a value that is already larger
+    if (lane == 0 && maxlev > __hip_atomic_load(&A.status->max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(&A.status->max_level, maxlev);
-    }
     const int nlev = min(maxlev, lev_cap);
     // first slot of every level in the group's sorted list (level 0 is empty), and the executor's work list: chunks of
     // at most 64 pairs, each inside one level, levels ascending
@@ -734,10 +734,9 @@ __device__ __forceinline__ void egg_pk_levels_mr_body(const EggPackedArgs &A) {
         maxlev = max(maxlev, wave_max[w]);
         over = over || wave_over[w];
     }
-    if (over && lane == 0) {
-        atomicExch(&A.status->fail_levels, 1);
+    if (over && lane == 0) atomicExch(&A.status->fail_levels, 1);
+    if (lane == 0 && maxlev > __hip_atomic_load(&A.status->max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(&A.status->max_level, maxlev);
-    }
     const int nlev = min(maxlev, lev_cap);
     uint32_t *lstart = A.lev_start + (size_t)g * (lev_cap + 2);
     uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
@@ -863,35 +862,40 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
         const uint32_t w = sorted[start + (uint32_t)lane];
         return ((uint32_t)lane < cnt) ? w : 0u;
     };
-    // Software pipeline over the static work list: descriptor four chunks ahead (scalar), entries three, particle
-    // constants two.  The rings of four stages are indexed with compile-time constants (the loop is unrolled by four),
-    // so nothing is copied and no load is waited for before its chunk is due.
-    uint32_t dsc[4], rec[4];
-    double2 wa[4], wb[4], pc[4];  // pc: what a pair's projection needs that does not depend on positions -- the refined
-                                  // reciprocal of its divisor and its minimum distance -- computed one chunk ahead, off
-                                  // the dependent chain of the chunk in progress
+    // Software pipeline over the static work list.  A chunk of a dense island is one level of its dependency chain --
+    // a few hundred cycles -- and every stage of the pipeline is a memory round trip of about that length: descriptor
+    // (scalar) -> entries -> the pairs' particle constants (gather) -> the position-independent part of the projection.
+    // Each stage therefore runs TWO chunks ahead of its consumer (one chunk ahead, the chunk in progress waited for
+    // the stage before it nearly every time).  The rings of eight are indexed with compile-time constants (the loop
+    // is unrolled by eight), so nothing is copied and no load is waited for before its chunk is due.
+    constexpr int R = 8, D_DSC = 7, D_REC = 5, D_WR = 3, D_PC = 1;
+    uint32_t dsc[R], rec[R];
+    double2 wa[R], wb[R], pc[R];  // pc: what a pair's projection needs that does not depend on positions -- the refined
+                                  // reciprocal of its divisor and its minimum distance -- computed ahead, off the
+                                  // dependent chain of the chunk in progress
     auto pair_constants = [&](double2 a, double2 b) {
         return make_double2(egg_rcp_refined((a.x + b.x) + compliance), overlap * (a.y + b.y));
     };
 #pragma unroll
-    for (int u = 0; u < 4; ++u) dsc[u] = load_desc(u);
+    for (int u = 0; u < D_DSC; ++u) dsc[u] = load_desc(u);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) rec[u] = load_rec(u, dsc[u]);
+    for (int u = 0; u < D_REC; ++u) rec[u] = load_rec(u, dsc[u]);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < D_WR; ++u) {
         wa[u] = gwr[rec[u] & 0x7FFFu];
         wb[u] = gwr[(rec[u] >> 16) & 0x7FFFu];
     }
-    pc[0] = pair_constants(wa[0], wb[0]);
-    for (int c0 = 0; c0 < nch; c0 += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < D_PC; ++u) pc[u] = pair_constants(wa[u], wb[u]);
+    for (int c0 = 0; c0 < nch; c0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
             const int c = c0 + u;
-            rec[(u + 3) & 3] = load_rec(c + 3, dsc[(u + 3) & 3]);
-            dsc[u] = load_desc(c + 4);
-            wa[(u + 2) & 3] = gwr[rec[(u + 2) & 3] & 0x7FFFu];
-            wb[(u + 2) & 3] = gwr[(rec[(u + 2) & 3] >> 16) & 0x7FFFu];
-            pc[(u + 1) & 3] = pair_constants(wa[(u + 1) & 3], wb[(u + 1) & 3]);
+            rec[(u + D_REC) & (R - 1)] = load_rec(c + D_REC, dsc[(u + D_REC) & (R - 1)]);
+            dsc[(u + D_DSC) & (R - 1)] = load_desc(c + D_DSC);
+            wa[(u + D_WR) & (R - 1)] = gwr[rec[(u + D_WR) & (R - 1)] & 0x7FFFu];
+            wb[(u + D_WR) & (R - 1)] = gwr[(rec[(u + D_WR) & (R - 1)] >> 16) & 0x7FFFu];
+            pc[(u + D_PC) & (R - 1)] = pair_constants(wa[(u + D_PC) & (R - 1)], wb[(u + D_PC) & (R - 1)]);
             const uint32_t r0 = rec[u];
             if (r0 >> 31) {
                 const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);

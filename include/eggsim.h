@@ -270,6 +270,9 @@ typedef struct {
     /* host wall time of _step's phases, summed since creation: [0] tiles and claims (re-clustering, packed plan), [1] uploads
      * and kernel launches, [2] waiting for the status block */
     double host_ms[3];
+    /* packed pipeline: the longest chain of dependent pairs in one collision pass of the most recent _step, per type -- the
+     * number of levels its executor ran one after the other (the path's latency floor: DESIGN.md section 4) */
+    int64_t max_levels[2];
 } egg_stats;
 int egg_get_stats(egg_handle *h, egg_stats *out);
 

@@ -6,6 +6,8 @@
   * the boundary's refusals: explicit particle counts <= 1 create nothing (L:79-85), state-changing calls
     between egg_step_begin and egg_step_end are rejected.
 Everything is compared bit for bit; the north star's 1e-4 relative tolerance is therefore met with zero difference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -162,6 +164,7 @@ def test_particles_closer_than_eps(egg, oracle_mod):
     assert x[0] == x[2] and y[0] == y[2] and x[1] == x[3] and y[1] == y[3]  # coincident twins never separate
 
 
+@pytest.mark.skipif(os.environ.get("EGGSIM_PACKED") == "1", reason="asserts the one-launch mode; EGGSIM_PACKED=1 forces the packed pipeline")
 def test_yolk_only_mass_change_between_fused_launches(egg, oracle_mod):
     """A yolk min/max mass change keeps the cell size, so no re-tiling (and none of its stream syncs) happens
     between the re-derivation kernel (L:1420-1430) and the next step -- which runs the yolk tiles inside the

@@ -259,3 +259,26 @@ def test_device_matches_the_committed_image(egg):
     image = h.draw(tuple(int(v) for v in g["screen"]), tuple(g["origin"]), interpolation_alpha=float(g["alpha"]))
     assert np.array_equal(image, g["image"])
     assert [h.render_canvas(w)[0].shape[:2] for w in (WHITE, YOLK)] == [tuple(s) for s in g["canvas_shapes"]]
+
+
+def test_canvas_cap_clips_the_splat(egg, oracle_mod, model):
+    """two blobs 2460 px apart: the canvas stops at 2560 px (L:1953-1954), centred on the common centroid, so both blobs
+    hang over its left / right edge and their quads are clipped there -- on both sides alike"""
+    h = egg.SimulationHandler()
+    o = oracle_mod.Oracle()
+    for x in (0.0, 2460.0):
+        h.add(x, 50.0, 50, 15)
+        o.add(x, 50.0, 50, 15)
+    for _ in range(2):
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+    image = h.draw((2760, 300), origin=(-150.0, -100.0), interpolation_alpha=1.0)
+    ref, canvases = _model_render(model, o, (2760, 300), 1.0, (-150.0, -100.0))
+    for w in (WHITE, YOLK):
+        canvas, (x0, _) = h.render_canvas(w)
+        assert canvas.shape[1] == 2560
+        _close(canvas, canvases[w], "canvas %d" % w)
+    white, (x0, _) = h.render_canvas(WHITE)
+    assert x0 == pytest.approx(1230.0 - 1280.0, abs=1.0)
+    assert white[:, 0, 3].max() > 0.5 and white[:, -1, 3].max() > 0.5  # cut through the blobs' density
+    _close(image, ref, "screen")

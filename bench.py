@@ -98,7 +98,7 @@ def cpu_baseline(n_batches, overlap, budget_s=12.0):
         o.update(1 / 60)
         steps += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or steps >= 400:
+        if dt >= budget_s or steps >= 2000:
             break
     pairs = o.total_visited - v0
     return {"value": pairs / dt, "unit": "pair-solves/s", "cores": 1, "kind": "port",
@@ -298,7 +298,10 @@ def main():
                        "batches_per_gpu": args.batches, "coincident_per_site": args.overlap,
                        "particles_per_gpu": int(n_white + n_yolk),
                        "parallelism": "slab%d" % world, "tiles": s1["n_tiles"], "retiles": s1["retiles"] - s0["retiles"],
-                       "redo_steps": s1["redo_steps"] - s0["redo_steps"], "path": "packed" if packed else "fused"},
+                       "redo_steps": s1["redo_steps"] - s0["redo_steps"], "path": "packed" if packed else "fused",
+                       # packed path: the longest chain of dependent pairs in one collision pass at the end of the run
+                       # (white, yolk) -- the levels its executor runs one after the other, i.e. the latency floor
+                       "levels_per_pass": s1.get("max_levels")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu,
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "dominant_kernel": dominant,

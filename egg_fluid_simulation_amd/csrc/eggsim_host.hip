@@ -295,7 +295,7 @@ struct egg_handle {
     int opt_levels_wd = 0;    // developer override of the multi-run walk's sub-wave width (16 or 32; 0 = by tile size)
     int opt_levels_mr = 1;    // packed pipeline: the level walk takes several runs per turn (0: one run per turn; A/B testing)
     int opt_packed = -1;      // packed pipeline: -1 automatic (large scenes), 0 never, 1 every eligible class
-    int opt_group_particles = 1280;  // particles one wave of the packed executor keeps in LDS (16 B each: 8 such waves fill a CU's 160 KiB)
+    int opt_group_particles = 0;  // particles one wave of the packed executor keeps in LDS (16 B each): 0 = by scene size (retile), at most 1280
     int opt_force_global_state = 0;  // test hook: run every tile through the global-memory-state kernel  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
     hipDeviceProp_t prop{};
     size_t lds_limit = 64 * 1024;  // dynamic LDS a step-kernel workgroup may use
@@ -996,7 +996,21 @@ int retile(egg_handle *h, int which) {
             pc.p_end = pn;
             // groups: consecutive tiles while one wave's LDS holds their positions (tiles are sorted by size, largest first)
             pc.meta_grp_geo = s.pk_meta_host.size();
-            const int64_t gp_max = std::max<int64_t>(h->opt_group_particles, tiles[(size_t)lc.first_tile].particles);
+            // Particles per executor wave.  1280 fills the lanes best on a full chip (eight 157-particle blobs: ~80 pairs
+            // per level).  While the class's groups are fewer than the chip's SIMDs the executor and the level walk are
+            // latency bound -- a level costs the same ~0.3 us whether its chunk holds 10 pairs or 64, two chunks of one
+            // level cost twice that -- so smaller groups (more waves, one chunk per level) are faster: measured ms per
+            // step with 320 / 640 / 1280 particles per group, 2048 blobs: 0.77 / 0.82 / 1.01, 4096: 1.03 / 0.94 / 0.99,
+            // 8192: 1.59 / 1.32 / 1.32.  Dense islands (four coincident blobs, 628 particles) keep 1280: 3.32 vs 3.54.
+            int64_t gp_auto = 1280;
+            if (tiles[(size_t)lc.first_tile].particles <= 256) {
+                int64_t class_particles = 0;
+                for (int t = 0; t < lc.n_tiles; ++t) class_particles += tiles[(size_t)lc.first_tile + t].particles;
+                const int64_t simds = 4 * (int64_t)std::max(1, h->prop.multiProcessorCount);
+                gp_auto = std::min<int64_t>(1280, std::max<int64_t>(320, (class_particles / simds + 159) / 160 * 160));
+            }
+            const int64_t gp_max = std::max<int64_t>(h->opt_group_particles > 0 ? h->opt_group_particles : gp_auto,
+                                                     tiles[(size_t)lc.first_tile].particles);
             int max_tiles_in_group = 0;
             for (int t = 0; t < lc.n_tiles;) {
                 int64_t in_group = 0;
@@ -2962,7 +2976,7 @@ int egg_set_option(egg_handle *h, int option, double value) {
             h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
             return EGG_OK;
         case EGG_OPT_GROUP_PARTICLES:
-            if (!(value >= 1 && value <= 10240)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "group particles must be in [1, 10240]");
+            if (!(value >= 0 && value <= 10240)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "group particles must be in [0, 10240]");
             h->opt_group_particles = (int)value;
             h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
             return EGG_OK;

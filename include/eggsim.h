@@ -294,7 +294,7 @@ enum {
     EGG_OPT_FORCE_GLOBAL_STATE,     /* test hook: 1 = every tile keeps its state in global memory (the large-island fallback) */
     EGG_OPT_FUSE_TYPES,             /* 1 (default): white and yolk tiles share one launch when the chip holds several tiles per CU; 0: one launch per type */
     EGG_OPT_PACKED,                 /* packed pipeline (one launch per phase, pair projections of many islands packed into full waves): -1 automatic (large scenes), 0 never, 1 whenever a launch class is eligible */
-    EGG_OPT_GROUP_PARTICLES         /* packed pipeline: particles whose positions one wave of the pair executor keeps in LDS (default 1280) */
+    EGG_OPT_GROUP_PARTICLES         /* packed pipeline: particles whose positions one wave of the pair executor keeps in LDS (0, the default: by scene size, 320..1280) */
 };
 int egg_set_option(egg_handle *h, int option, double value);
 

@@ -2,7 +2,7 @@
 # batch-count sweep for profiles/r02_batch_sweep.md (run on the GPU box)
 out=gpurun_out/sweep_r02.txt
 : > $out
-for cfg in "--batches 256 --overlap 1" "--batches 1024 --overlap 1" "--batches 4096 --overlap 1" "--batches 16384 --overlap 1" "--batches 65536 --overlap 1" "--batches 4096 --overlap 4" "--batches 16384 --overlap 4"; do
+for cfg in "--batches 256 --overlap 1" "--batches 1024 --overlap 1" "--batches 2048 --overlap 1" "--batches 4096 --overlap 1" "--batches 8192 --overlap 1" "--batches 16384 --overlap 1" "--batches 65536 --overlap 1" "--batches 4096 --overlap 4" "--batches 16384 --overlap 4"; do
   echo "== $cfg" >> $out
   timeout -k 10 300 python bench.py $cfg --steps 60 --warmup 10 --no-cpu-baseline --no-latency 2>/dev/null | tail -1 >> $out || echo "FAILED rc=$?" >> $out
 done

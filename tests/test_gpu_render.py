@@ -282,3 +282,20 @@ def test_canvas_cap_clips_the_splat(egg, oracle_mod, model):
     assert x0 == pytest.approx(1230.0 - 1280.0, abs=1.0)
     assert white[:, 0, 3].max() > 0.5 and white[:, -1, 3].max() > 0.5  # cut through the blobs' density
     _close(image, ref, "screen")
+
+
+def test_drawing_does_not_disturb_the_solver(egg):
+    """draw() between steps (its kernels share the white stream, its reductions read both state buffers) leaves the
+    particle state of a moving scene exactly where a run without drawing puts it"""
+    def run(draw):
+        h = egg.SimulationHandler()
+        ids = [h.add(100.0 + 130.0 * k, 100.0 + 40.0 * (k % 2), 50, 15) for k in range(5)]
+        for step in range(12):
+            for k, i in enumerate(ids):
+                h.set_target_position(i, 100.0 + 130.0 * k + 15.0 * step, 100.0 + 40.0 * (k % 2) - 9.0 * step)
+            h.update(1 / 60)
+            if draw and step % 2 == 0:
+                h.draw((320, 240), origin=(0.0, 0.0), interpolation_alpha=0.5)
+        return [h.download(w, f) for w in (WHITE, YOLK) for f in ("x", "y", "vx", "vy", "last_x", "last_y")]
+    plain, drawn = run(False), run(True)
+    assert all(np.array_equal(a, b) for a, b in zip(plain, drawn))

@@ -160,6 +160,7 @@ struct EggPackedArgs {
     int32_t *tile_visits;      // [EGG_PK_MAX_PASSES][n_tiles] n_collided of each pass (L:1657)
     int32_t *tile_need;        // [EGG_PK_MAX_PASSES][n_tiles] visit entries each pass needed (list capacity check)
     int32_t *tile_slack;       // [n_tiles]
+    int32_t *tile_fast;        // [n_tiles] 1: every pair of the tile may take the hand-expanded arithmetic (found by the step's first list pass)
     int32_t lcap, scap, lev_cap, sort_cap, chunk_cap;
     // LDS geometry of egg_pk_lists
     int32_t nmax, amax, ccap, use_grid, stage_cap;

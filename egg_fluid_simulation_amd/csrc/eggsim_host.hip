@@ -1083,7 +1083,7 @@ int retile(egg_handle *h, int which) {
             HIP_TRY(h, s.pk_chunks.reserve(s.pk_chunk_words + 64, false, s.stream));
             HIP_TRY(h, s.pk_nchunks.reserve(2 * ng + 8, false, s.stream));
             HIP_TRY(h, s.pk_levstart.reserve(ng * ((size_t)s.pk_lev_cap + 2) + 64, false, s.stream));
-            HIP_TRY(h, s.pk_tile.reserve(nt * (2 + 2 * EGG_PK_MAX_PASSES) + 4, false, s.stream));
+            HIP_TRY(h, s.pk_tile.reserve(nt * (3 + 2 * EGG_PK_MAX_PASSES) + 4, false, s.stream));
         }
         s.pk_plan_dirty = true;
     }
@@ -1275,11 +1275,12 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.grp_nchunks = s.pk_nchunks.p + pc.group_base;
     A.grp_nlev = s.pk_nchunks.p + s.pk_groups + pc.group_base;
     A.lev_start = s.pk_levstart.p + (size_t)pc.group_base * ((size_t)s.pk_lev_cap + 2);
-    int32_t *tb = s.pk_tile.p + (size_t)pc.tile_base * (2 + 2 * EGG_PK_MAX_PASSES);
+    int32_t *tb = s.pk_tile.p + (size_t)pc.tile_base * (3 + 2 * EGG_PK_MAX_PASSES);
     A.tile_total = tb;
     A.tile_slack = tb + pc.n_tiles;
-    A.tile_visits = tb + 2 * (size_t)pc.n_tiles;
-    A.tile_need = tb + (2 + (size_t)EGG_PK_MAX_PASSES) * (size_t)pc.n_tiles;
+    A.tile_fast = tb + 2 * (size_t)pc.n_tiles;
+    A.tile_visits = tb + 3 * (size_t)pc.n_tiles;
+    A.tile_need = tb + (3 + (size_t)EGG_PK_MAX_PASSES) * (size_t)pc.n_tiles;
     A.lcap = pc.lcap;
     A.scap = pc.scap;
     A.lev_cap = s.pk_lev_cap;

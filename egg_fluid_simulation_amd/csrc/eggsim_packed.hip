@@ -335,12 +335,21 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     // Sufficient per particle: eps / 2 <= w <= 2^298 and |overlap * r| <= 2^298, with the compliance <= 2^298: then
     // eps <= w_i + w_j, eps <= divisor <= 2^300 and min_distance^2 <= 2^600 for every pair (floating-point addition is
     // monotonic; NaN fails the comparisons).  Nearly always true; the per-pair test then drops out of the fill.
-    bool mine_fast = A.collision_compliance <= 0x1p298;
-    for (int i = tid; i < n; i += nthreads) {
-        const double2 w = ((const double2 *)A.pk_wr)[p0 + i];
-        mine_fast = mine_fast && (w.x >= A.eps * 0.5) && (w.x <= 0x1p298) && (fabs(A.overlap_factor * w.y) <= 0x1p298);
+    // (masses and radii do not change inside a step: the first list pass of the step decides, the later ones read the
+    // answer -- the test costs a 16-byte load per particle, as much as the positions)
+    bool all_fast;
+    if (A.pass_seq == 0) {
+        bool mine_fast = A.collision_compliance <= 0x1p298;
+        for (int i = tid; i < n; i += nthreads) {
+            const double2 w = ((const double2 *)A.pk_wr)[p0 + i];
+            mine_fast = mine_fast && (w.x >= A.eps * 0.5) && (w.x <= 0x1p298) && (fabs(A.overlap_factor * w.y) <= 0x1p298);
+        }
+        all_fast = __syncthreads_and(mine_fast) != 0;
+        if (tid == 0) A.tile_fast[tile] = all_fast ? 1 : 0;
+    } else {
+        all_fast = A.tile_fast[tile] != 0;
+        __syncthreads();  // t.aclaim is read below
     }
-    const bool all_fast = __syncthreads_and(mine_fast) != 0;
 
     // ----------------------------------- spatial hash of this pass, L:1486-1511 (claim check as in egg_step_body)
     bool bad = false;

@@ -313,15 +313,19 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
 
     // everything about the tile in one 32-byte record (a chain of dependent loads here -- tile -> atoms -> counts ->
     // claims -- cost five memory round trips with the whole workgroup waiting)
-    const int4 geo0 = ((const int4 *)A.tile_geo)[2 * tile], geo1 = ((const int4 *)A.tile_geo)[2 * tile + 1];
-    const int p0 = __builtin_amdgcn_readfirstlane(geo0.x), n = __builtin_amdgcn_readfirstlane(min(geo0.y, A.nmax));
-    const int a_begin = __builtin_amdgcn_readfirstlane(geo0.z), na = __builtin_amdgcn_readfirstlane(min(geo0.w, A.amax));
-    const int org_x = __builtin_amdgcn_readfirstlane(geo1.x), org_y = __builtin_amdgcn_readfirstlane(geo1.y);
+    // (wave-uniform: through the constant address space it arrives by ONE scalar load, beside the vector memory
+    // pipeline; the record was written by the host or by an earlier launch)
+    typedef const __attribute__((address_space(4))) int32_t egg_const_i32;
+    egg_const_i32 *geo = (egg_const_i32 *)(uintptr_t)(A.tile_geo + 8 * (size_t)tile);
+    const int p0 = geo[0], n = min(geo[1], A.nmax);
+    const int a_begin = geo[2], na = min(geo[3], A.amax);
+    const int org_x = geo[4], org_y = geo[5];
+    const int geo_w = geo[6], geo_h = geo[7];
     t.na = na;
     t.n = n;
-    t.gw = __builtin_amdgcn_readfirstlane(geo1.z);
-    const int gh = __builtin_amdgcn_readfirstlane(geo1.w);
-    t.ncell = A.use_grid ? __builtin_amdgcn_readfirstlane((int)min((long long)geo1.z * geo1.w, (long long)A.ccap)) : A.ccap;
+    t.gw = geo_w;
+    const int gh = geo_h;
+    t.ncell = A.use_grid ? (int)min((long long)geo_w * geo_h, (long long)A.ccap) : A.ccap;
     for (int k = tid; k < na; k += nthreads) ((int4 *)t.aclaim)[k] = ((const int4 *)A.tile_claims)[a_begin + k];
     const int cur = 0, prev = 1;  // LDS generation buffers of this launch
     uint32_t *g_ckey_cur = A.pk_ckey + (size_t)(A.substep & 1) * A.pk_stride + p0;

@@ -299,3 +299,33 @@ def test_drawing_does_not_disturb_the_solver(egg):
         return [h.download(w, f) for w in (WHITE, YOLK) for f in ("x", "y", "vx", "vy", "last_x", "last_y")]
     plain, drawn = run(False), run(True)
     assert all(np.array_equal(a, b) for a, b in zip(plain, drawn))
+
+
+def test_other_particle_radii_change_texture_and_quads(egg, oracle_mod, model):
+    """white radii 3..5 px (per-particle radius from the mass distribution, L:955-962), yolk radius 6: the density
+    texture is sized by the LARGER max_radius (L:626-629), every quad by its own particle's radius"""
+    white, yolk = egg.default_configs()
+    white = dict(white, min_radius=3.0, max_radius=5.0)
+    yolk = dict(yolk, min_radius=6.0, max_radius=6.0)
+    h = egg.SimulationHandler(dict(white), dict(yolk))
+    from oracle.oracle import CONFIG_KEYS  # the oracle takes the solver keys only
+    o = oracle_mod.Oracle({k: white[k] for k in CONFIG_KEYS}, {k: yolk[k] for k in CONFIG_KEYS})
+    for x, y in ((100.0, 100.0), (260.0, 130.0)):
+        assert h.add(x, y, 50, 15) == o.add(x, y, 50, 15)
+    for s in (h, o):
+        s.set_target_position(2, 420.0, 260.0)
+    for _ in range(4):
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+    assert np.array_equal(h.download(WHITE, "x"), o.field(WHITE, "x"))
+    radii = h.download(WHITE, "radius")
+    assert radii.min() >= 3.0 and radii.max() <= 5.0 and np.unique(radii).size > 20
+    assert h.particle_texture().shape == (54, 54)  # (6 * 4 + 3) * 2
+    image = h.draw((480, 400), (-20.0, -20.0), interpolation_alpha=0.75)
+    states = [_state(o, w) for w in (WHITE, YOLK)]
+    ref, canvases = model.render(states, [o.env(w) for w in (WHITE, YOLK)], model.DEFAULT_RENDER,
+                                 [np.ones((s["x"].size, 4), np.float32) for s in states], (480, 400), 0.75, (-20.0, -20.0),
+                                 max_radius=(5.0, 6.0))
+    for w in (WHITE, YOLK):
+        _close(h.render_canvas(w)[0], canvases[w], "canvas %d" % w)
+    _close(image, ref, "screen")

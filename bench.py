@@ -161,8 +161,10 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the config-2 latency block")
     ap.add_argument("--packed", type=int, default=-1, help="packed pipeline: -1 automatic, 0 never, 1 always (A/B testing)")
     ap.add_argument("--group-particles", type=int, default=0, help="packed pipeline: particles per executor wave (0 = default)")
-    ap.add_argument("--profile-steps", type=int, default=20, help="steps of the per-kernel timing leg after the timed region")
+    ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the per-kernel timing leg (a replay of the timed region on a fresh scene; -1: as many as --steps, 0: none)")
     args = ap.parse_args()
+    if args.profile_steps < 0:
+        args.profile_steps = args.steps
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -187,17 +189,22 @@ def main():
     from egg_fluid_simulation_amd import WHITE, YOLK, SimulationHandler, _ffi
     from egg_fluid_simulation_amd.sharding import BoundaryExchange
 
-    h = SimulationHandler(device=local_rank)  # raises without a GPU: no CPU path
-    if args.tile_target:
-        h.set_option(_ffi.OPT_TILE_TARGET_PARTICLES, args.tile_target)
-    if args.no_fuse:
-        h.set_option(_ffi.OPT_FUSE_TYPES, 0)
-    if args.packed >= 0:
-        h.set_option(_ffi.OPT_PACKED, args.packed)
-    if args.group_particles:
-        h.set_option(_ffi.OPT_GROUP_PARTICLES, args.group_particles)
     xs, ys, side = grid_positions(args.batches, column_offset=rank, overlap=args.overlap)
-    h.add_many(xs, ys, 50, 15)
+
+    def make_handler():
+        hh = SimulationHandler(device=local_rank)  # raises without a GPU: no CPU path
+        if args.tile_target:
+            hh.set_option(_ffi.OPT_TILE_TARGET_PARTICLES, args.tile_target)
+        if args.no_fuse:
+            hh.set_option(_ffi.OPT_FUSE_TYPES, 0)
+        if args.packed >= 0:
+            hh.set_option(_ffi.OPT_PACKED, args.packed)
+        if args.group_particles:
+            hh.set_option(_ffi.OPT_GROUP_PARTICLES, args.group_particles)
+        hh.add_many(xs, ys, 50, 15)
+        return hh
+
+    h = make_handler()
     n_white, n_yolk = h.get_n_particles()
     pitch = site_pitch(args.overlap)
     halo = BoundaryExchange(h, rank, world, slab_lo=100.0 + pitch * rank * side - pitch / 2,
@@ -232,14 +239,24 @@ def main():
     else:
         total_particles = float(n_white + n_yolk)
 
-    # per-kernel leg (outside the timed region): HIP events around every launch of the packed pipeline
+    # per-kernel leg (outside the timed region): HIP events around every launch of the packed pipeline.  The scenes are
+    # not stationary (config 3's dependency chains deepen step by step), so the leg REPLAYS the timed region's steps
+    # on a fresh scene -- the same steps a `rocprofv3 --kernel-trace --stats` of this command averages over
     per_kernel = None
     if rank == 0 and s1["packed"][WHITE] and args.profile_steps > 0:
-        h.set_option(_ffi.OPT_TIMING, 2)
+        hp = h
+        if world == 1:
+            hp = make_handler()
+            for _ in range(args.warmup):
+                hp.step(1 / 60, 2, 3)
+        # (several ranks: rank 0 carries on with its own slab, without the exchange)
+        hp.set_option(_ffi.OPT_TIMING, 2)
         for _ in range(args.profile_steps):
-            one_step() if halo is None else h.step(1 / 60, 2, 3)
-        h.synchronize()
-        sp = h.stats()
+            hp.step(1 / 60, 2, 3)
+        hp.synchronize()
+        sp = hp.stats()
+        if hp is not h:
+            del hp
         per_kernel = []
         for w, tag in ((WHITE, "white"), (YOLK, "yolk")):
             for k, name in enumerate(_ffi.PK_KINDS):
@@ -254,8 +271,9 @@ def main():
         steps_per_sec = args.steps / elapsed
         fused = bool(s1.get("fused_launch"))
         packed = bool(s1["packed"][WHITE])
-        note = "592 B/particle/step byte model of SURVEY.md 8d; this path is bound by FP64 / integer instruction issue " \
-               "along the pair-dependency order, not by HBM bytes: see `traffic`, `valu` and DESIGN.md"
+        note = "592 B/particle/step byte model of SURVEY.md 8d; this path is bound by the reference's sequential pair order " \
+               "(config.levels_per_pass dependent levels per collision pass at ~0.3 us each, plus the walk that finds " \
+               "them), not by HBM bytes: see `traffic`, `valu` and DESIGN.md section 4"
         if packed and per_kernel:
             white = [k for k in per_kernel if k["type"] == "white"]
             # all launches stepping the white particles: HIP events around the white stream's launches of a step, inside

@@ -1,6 +1,7 @@
 /* Plain C99 caller of the C ABI (include/eggsim.h): what a LuaJIT ffi.cdef binding does, without Lua.
  * Prints the status of egg_create; with a device: adds two batches, steps `n` times through egg_update and
- * prints every batch position with 17 significant digits (the test compares them with the oracle's). */
+ * prints every batch position with 17 significant digits (the test compares them with the oracle's), then draws the
+ * scene through egg_render into a 240 x 200 float image and prints a few pixels and the image's sum. */
 #include <stdio.h>
 #include <stdlib.h>
 #include "eggsim.h"
@@ -34,6 +35,29 @@ int main(int argc, char **argv) {
     printf("position %lld %.17g %.17g\n", (long long)b, x, y);
     if (egg_get_position(h, 99, &x, &y) != EGG_ERR_UNKNOWN_ID) return 1; /* the reference throws here */
     printf("unknown id: %s\n", egg_last_error(h));
+    {
+        egg_render_params p;
+        egg_default_render_params(&p);
+        p.screen_w = 240;
+        p.screen_h = 200;
+        p.origin_x = 300.0;
+        p.origin_y = 200.0;
+        p.interpolation_alpha = 1.0;
+        float *image = (float *)malloc(sizeof(float) * 4 * 240 * 200);
+        if (!image || egg_render(h, &p, image) != EGG_OK) {
+            fprintf(stderr, "render failed: %s\n", egg_last_error(h));
+            return 1;
+        }
+        const int probes[4][2] = {{100, 100}, {140, 96}, {171, 120}, {5, 5}};
+        for (int k = 0; k < 4; ++k) {
+            const float *px = image + 4 * (probes[k][1] * 240 + probes[k][0]);
+            printf("pixel %d %d %.9g %.9g %.9g %.9g\n", probes[k][0], probes[k][1], px[0], px[1], px[2], px[3]);
+        }
+        double sum = 0;
+        for (int k = 0; k < 4 * 240 * 200; ++k) sum += image[k];
+        printf("image sum %.17g\n", sum);
+        free(image);
+    }
     egg_destroy(h);
     return 0;
 }

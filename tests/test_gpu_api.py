@@ -162,6 +162,16 @@ def test_plain_c_caller_matches_the_oracle(egg, oracle_mod, tmp_path):
         _, bid, x, y = line.split()
         assert int(bid) == i and (float(x), float(y)) == o.get_position(i), line
     assert out[3].startswith("unknown id:") and "no batch with id" in out[3]
+    # ... and its egg_render image is the CPU model's of the draw path (oracle/render_model.py), pixel for pixel
+    from oracle import render_model as model
+    states = [{k: o.field(w, k) for k in ("x", "y", "last_x", "last_y", "vx", "vy", "radius")} for w in (WHITE, YOLK)]
+    ref, _ = model.render(states, [o.env(w) for w in (WHITE, YOLK)], model.DEFAULT_RENDER,
+                          [np.ones((s["x"].size, 4), np.float32) for s in states], (240, 200), 1.0, (300.0, 200.0))
+    for line in out[4:8]:
+        _, px, py, r, g, b, a = line.split()
+        assert np.array_equal(np.float32([r, g, b, a]), ref[int(py), int(px)]), line
+    assert ref[100, 100, 3] == 1.0 and ref[5, 5, 3] == 0.0  # an egg and the empty corner
+    assert float(out[8].split()[2]) == float(np.cumsum(ref.reshape(-1).astype(np.float64))[-1])  # (cumsum: added up in order, like the C loop)
 
 
 def test_unsupported_configuration_fails_loudly(egg):

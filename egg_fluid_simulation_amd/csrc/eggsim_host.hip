@@ -934,13 +934,15 @@ int retile(egg_handle *h, int which) {
         // automatic: scenes large enough that the chip is full of tiles whatever the kernel (the fused kernel's
         // latency per step is lower while every tile has a CU almost to itself); judged on the white tiles so
         // that both types of a scene take the same path
-        // Measured crossover on MI355X (ms per step, fused vs packed): separate 157-particle blobs 1536: 0.78 / 0.78,
-        // 2048: 1.06 / 1.04, 3072: 1.39 / 0.90; dense 628-particle islands 256: 1.60 / 2.72, 1024: 5.9 / 3.2 -- the packed
-        // pipeline has a latency floor per collision pass, the fused kernel's time grows with the tiles per CU.
+        // Measured crossover on MI355X (ms per step, fused vs packed): separate 157-particle blobs 1024: 0.58 / 0.68,
+        // 1536: 0.78 / 0.73, 2048: 1.06 / 0.79, 3072: 1.38 / 0.86; dense 628-particle islands 192: 1.65 / 2.79, 256: 1.71 /
+        // 2.82, 320: 2.99 / 2.85, 512: 3.20 / 2.92, 768: 4.92 / 3.09 -- the packed pipeline has a latency floor per
+        // collision pass; the fused kernel's time grows with the tiles per CU, and a dense island fills a CU: from the
+        // first CU that gets two, its step takes twice as long.
         if (which == 0) {
             const int64_t cus = std::max(1, h->prop.multiProcessorCount);
             const bool dense = !tiles.empty() && tiles.front().particles > 256;
-            h->packed_auto = (int64_t)tiles.size() >= (dense ? 2 : 6) * cus;
+            h->packed_auto = dense ? (int64_t)tiles.size() > cus : (int64_t)tiles.size() >= 6 * cus;
         }
         const bool want = h->opt_packed > 0 || (h->opt_packed < 0 && h->packed_auto);
         const bool allowed = want && !single && s.gens <= 2 && s.pk_allowed;

@@ -329,3 +329,54 @@ def test_other_particle_radii_change_texture_and_quads(egg, oracle_mod, model):
     for w in (WHITE, YOLK):
         _close(h.render_canvas(w)[0], canvases[w], "canvas %d" % w)
     _close(image, ref, "screen")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_render_settings_match_the_model(egg, oracle_mod, model, seed):
+    """random render keys, thresholds, colours, screen placement and interpolation on one small scene"""
+    import copy
+    rng = np.random.default_rng(seed)
+    white, yolk = egg.default_configs()
+    cfgs = []
+    for base in (white, yolk):
+        cfgs.append(dict(color=[float(v) for v in rng.uniform(0.2, 1.0, 4)], outline_color=[float(v) for v in rng.uniform(0.0, 1.0, 4)],
+                         outline_thickness=float(rng.choice([0.0, 0.5, 1.0, 2.0, 3.7])), highlight_strength=float(rng.choice([0.0, 0.5, 2.0])),
+                         shadow_strength=float(rng.choice([0.0, 0.3, 1.5])), texture_scale=float(rng.uniform(6.0, 14.0)),
+                         motion_blur=float(rng.choice([0.0, 0.0003, 0.004]))))
+    h = egg.SimulationHandler(dict(white, **copy.deepcopy(cfgs[0])), dict(yolk, **copy.deepcopy(cfgs[1])))
+    h._use_particle_color = bool(rng.integers(2))
+    h._use_lighting = bool(rng.integers(2))
+    h._thresholding_threshold = float(rng.uniform(0.15, 0.6))
+    h._thresholding_smoothness = float(rng.uniform(0.005, 0.05))
+    o = oracle_mod.Oracle()
+    spots = [(float(x), float(y)) for x, y in rng.uniform(60.0, 260.0, (3, 2))]
+    batch_colors = []
+    for x, y in spots:
+        wc, yc = [float(v) for v in rng.uniform(0, 1, 4)], [float(v) for v in rng.uniform(0, 1, 4)]
+        h.add(x, y, 30.0, 12.0, white_color=wc, yolk_color=yc)
+        o.add(x, y, 30.0, 12.0)
+        batch_colors.append((wc, yc))
+    target = (float(rng.uniform(0, 400)), float(rng.uniform(0, 400)))
+    for s in (h, o):
+        s.set_target_position(2, *target)
+    for _ in range(int(rng.integers(2, 7))):
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+    assert np.array_equal(h.download(WHITE, "x"), o.field(WHITE, "x")) and np.array_equal(h.download(YOLK, "vy"), o.field(YOLK, "vy"))
+    n = [o.n_particles(w) // 3 for w in (WHITE, YOLK)]
+    if h._use_particle_color:
+        colors = [np.concatenate([np.tile(np.float32(bc[w]), (n[w], 1)) for bc in batch_colors]) for w in (WHITE, YOLK)]
+    else:
+        colors = [np.ones((3 * n[w], 4), np.float32) for w in (WHITE, YOLK)]
+    size = (int(rng.integers(200, 420)), int(rng.integers(180, 400)))
+    origin = (float(rng.uniform(-60, 60)), float(rng.uniform(-60, 60)))
+    t = float(rng.uniform(0, 1))
+    instancing = bool(rng.integers(2))
+    params = dict(use_particle_color=h._use_particle_color, use_lighting=h._use_lighting, use_instancing=instancing,
+                  threshold=h._thresholding_threshold, smoothness=h._thresholding_smoothness)
+    clear = tuple(float(v) for v in rng.uniform(0, 1, 4))
+    image = h.draw(size, origin, interpolation_alpha=t, clear=clear, use_instancing=instancing)
+    ref, canvases = _model_render(model, o, size, t, origin, cfgs, colors, params, clear=clear)
+    for w in (WHITE, YOLK):
+        _close(h.render_canvas(w)[0], canvases[w], "canvas %d" % w)
+    _close(image, ref, "screen")

@@ -20,6 +20,20 @@ int main() {
             if (rep) printf("tiny kernel, grid %d: %.2f us per dependent launch\n", grid, 1e3 * ms / 2000);
         }
     }
+    {   // the same chain as a graph (captured once, launched repeatedly)
+        hipGraph_t graph; hipGraphExec_t exec;
+        hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+        for (int k = 0; k < 200; ++k) hipLaunchKernelGGL(tiny, dim3(512), dim3(64), 0, s, d);
+        hipStreamEndCapture(s, &graph);
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(a, s);
+            for (int k = 0; k < 10; ++k) hipGraphLaunch(exec, s);
+            hipEventRecord(b, s); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (rep) printf("graph of 200 dependent tiny kernels, grid 512: %.2f us per kernel\n", 1e3 * ms / 2000);
+        }
+    }
     for (long long ticks : {2000LL, 10000LL}) {   // 100 MHz counter: 20 us / 100 us of work
         hipEventRecord(a, s);
         for (int k = 0; k < 500; ++k) hipLaunchKernelGGL(spin, dim3(512), dim3(64), 0, s, d, ticks);

@@ -49,6 +49,7 @@ extern "C" __global__ void egg_pk_levels64_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels_mr16_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels_mr32_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_exec_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_exec_chain_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_sort_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_sort_direct_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_end_kernel(EggPackedArgs A);
@@ -1371,7 +1372,9 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
             launch_all(EGG_PK_KIND_SORT, [](const PackedClass &pc) { return pc.lds_sort ? egg_pk_sort_kernel : egg_pk_sort_direct_kernel; },
                        groups_of, c256,
                        [&](const PackedClass &pc) { return pc.lds_sort ? pc.lds_sort : egg_align16((size_t)(s.pk_lev_cap + 2) * 4); });
-            launch_all(EGG_PK_KIND_EXEC, [](const PackedClass &) { return egg_pk_exec_kernel; }, groups_of, c64,
+            // (fewer groups than SIMDs: every executor wave is alone, its time is levels x chain latency)
+            const int simds = 4 * std::max(1, h->prop.multiProcessorCount);
+            launch_all(EGG_PK_KIND_EXEC, [&](const PackedClass &pc) { return pc.n_groups <= simds ? egg_pk_exec_chain_kernel : egg_pk_exec_kernel; }, groups_of, c64,
                        [](const PackedClass &pc) { return pc.lds_exec; });
         }
     }
@@ -1913,7 +1916,7 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
         if (e == hipSuccess)
             for (const void *f : {(const void *)egg_pk_lists_fresh_kernel, (const void *)egg_pk_lists_stale_kernel,
                                   (const void *)egg_pk_levels8_kernel, (const void *)egg_pk_levels16_kernel,
-                                  (const void *)egg_pk_levels64_kernel, (const void *)egg_pk_exec_kernel,
+                                  (const void *)egg_pk_levels64_kernel, (const void *)egg_pk_exec_kernel, (const void *)egg_pk_exec_chain_kernel,
                                   (const void *)egg_pk_sort_kernel, (const void *)egg_pk_levels_mr16_kernel,
                                   (const void *)egg_pk_levels_mr32_kernel, (const void *)egg_render_splat_kernel})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);

@@ -837,7 +837,11 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_direct_kernel(EggP
 // wave-instruction.  The work list is static, so everything but the positions runs ahead of the arithmetic: the
 // chunk descriptors come by scalar loads, the entries are requested three chunks ahead, the (inverse mass, radius)
 // records of both particles two chunks ahead; the positions are read when they are needed -- from LDS.
-extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArgs A) {
+// PREDICATED: the projection without branches on its chain (project_pair_predicated) -- for launches whose waves are
+// alone on their SIMDs (time = levels x chain latency); on a full chip the branches skip work that the lanes of other
+// waves could use, and win by 2 %.
+template <bool PREDICATED>
+__device__ __forceinline__ void egg_pk_exec_body(const EggPackedArgs &A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
@@ -910,7 +914,18 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
             wb[(u + D_WR) & (R - 1)] = gwr[(rec[(u + D_WR) & (R - 1)] >> 16) & 0x7FFFu];
             pc[(u + D_PC) & (R - 1)] = pair_constants(wa[(u + D_PC) & (R - 1)], wb[(u + D_PC) & (R - 1)]);
             const uint32_t r0 = rec[u];
-            if (r0 >> 31) {
+            if (PREDICATED) {
+                // (lanes without a pair read particle 0 of the group and write nothing)
+                const bool has_pair = (r0 >> 31) != 0;
+                const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
+                double2 pa = lpos[ga], pb = lpos[gb];
+                project_pair_predicated([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
+                                        has_pair, (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], pc[u], overlap, compliance, eps);
+                if (has_pair) {
+                    lpos[ga] = pa;
+                    lpos[gb] = pb;
+                }
+            } else if (r0 >> 31) {
                 const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
                 double2 pa = lpos[ga], pb = lpos[gb];
                 project_pair<true>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
@@ -922,6 +937,8 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
     }
     for (int i = lane; i < np; i += 64) gpos[i] = lpos[i];
 }
+extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArgs A) { egg_pk_exec_body<false>(A); }
+extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_chain_kernel(EggPackedArgs A) { egg_pk_exec_body<true>(A); }
 
 // ------------------------------------------------------------------------------------------------
 // End of a step: post-solve of the last sub-step (L:1690-1693), scatter to particle order, per-atom cell boxes

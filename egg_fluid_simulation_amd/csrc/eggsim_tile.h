@@ -298,6 +298,50 @@ __device__ __forceinline__ void project_pair(SameBatch same_batch, bool slow, do
     }
 }
 
+// project_pair<true> without branches on its dependent chain, for the packed executor: one wave walks an island's
+// levels and every level waits for the one before it, so a compare + exec-mask branch in the middle of the chain (two of
+// them in project_pair) is dead time for the whole island.  All lanes run the hand-expanded arithmetic on whatever they
+// hold (no traps; garbage stays in the lane), the results are taken by select where the reference would have taken
+// them, and only the rare pairs outside the arithmetic window (or flagged slow) branch, afterwards, into the reference
+// path from the unchanged inputs.  Same operations in the same order as project_pair: same bits.
+template <class SameBatch>
+__device__ __forceinline__ void project_pair_predicated(SameBatch same_batch, bool active, bool slow, double2 &pa, double2 &pb,
+                                                        double2 wra, double2 wrb, double2 cached, double overlap,
+                                                        double compliance, double eps) {
+    const double dx = pb.x - pa.x, dy = pb.y - pa.y;
+    const double d2 = dx * dx + dy * dy;
+    const double min_distance = cached.y;
+    const double md2 = min_distance * min_distance;
+    const bool in_range = active && (((int)(d2 <= md2) | (int)slow) != 0);
+    double current, r_current;
+    egg_sqrt_rcp_core(d2, current, r_current);
+    const double violation = current - min_distance;
+    const bool fast = ((int)!slow & (int)(current >= eps) & (int)(fabs(dx) >= EGG_ARITH_LO) & (int)(fabs(dy) >= EGG_ARITH_LO) &
+                       (int)(fabs(violation) >= EGG_ARITH_LO)) != 0;
+    const double wa = wra.x, wb = wrb.x;
+    const double divisor = (wa + wb) + compliance;
+    const double nx = egg_div_with_rcp(dx, current, r_current);
+    const double ny = egg_div_with_rcp(dy, current, r_current);
+    double correction = egg_div_with_rcp(-violation, divisor, cached.x);
+    __asm__("v_max_f64 %0, %1, -|%2|" : "=v"(correction) : "v"(correction), "v"(violation));
+    __asm__("v_min_f64 %0, %1, |%2|" : "=v"(correction) : "v"(correction), "v"(violation));
+    const double tx = nx * correction, ty = ny * correction;
+    const double ax = pa.x + -tx * wa, ay = pa.y + -ty * wa;
+    const double bx = pb.x + tx * wb, by = pb.y + ty * wb;
+    const bool take = in_range && fast;
+    const double2 pa0 = pa, pb0 = pb;
+    pa.x = take ? ax : pa.x;
+    pa.y = take ? ay : pa.y;
+    pb.x = take ? bx : pb.x;
+    pb.y = take ? by : pb.y;
+    if (__builtin_expect(in_range && !fast, 0)) {  // (behind the selects: the common case falls through one untaken branch)
+        double2 qa = pa0, qb = pb0;
+        project_pair_reference(same_batch, qa, qb, wra, wrb, overlap, compliance, eps);
+        pa = qa;
+        pb = qb;
+    }
+}
+
 // Hash generations.  The reference clears the cell lists and `collided` only BETWEEN the collision passes
 // of a sub-step (L:1905-1912), so the first pass of a later sub-step still sees the previous pass (Q3);
 // with a single collision pass per sub-step nothing is ever cleared inside a step and every sub-step

@@ -1043,10 +1043,10 @@ int retile(egg_handle *h, int which) {
             }
             const size_t sort_words = (size_t)max_tiles_in_group * (size_t)pc.scap + 64;
             pc.chunk_cap = (int)std::min<size_t>(sort_words / 64 + (size_t)s.pk_lev_cap + 8, (size_t)1 << 28);
-            pc.lds_exec = (size_t)pc.max_group_particles * 16;
+            pc.lds_exec = (size_t)pc.max_group_particles * 16;  // (the chain variant adds a spare slot per lane at launch: 1,280 particles + 64 would cost the eighth wave of a CU)
             pc.lds_sort = egg_align16((size_t)(s.pk_lev_cap + 2) * 4) + sort_words * 4;
             if (pc.lds_sort > 64 * 1024) pc.lds_sort = 0;
-            if (pc.lds_exec > h->lds_limit || pc.lds_levels > h->lds_limit || sort_words >= ((size_t)1 << 26)) {
+            if (pc.lds_exec + 64 * 16 > h->lds_limit || pc.lds_levels > h->lds_limit || sort_words >= ((size_t)1 << 26)) {
                 s.pk_meta_host.resize(meta_mark);
                 continue;
             }
@@ -1375,7 +1375,7 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
             // (fewer groups than SIMDs: every executor wave is alone, its time is levels x chain latency)
             const int simds = 4 * std::max(1, h->prop.multiProcessorCount);
             launch_all(EGG_PK_KIND_EXEC, [&](const PackedClass &pc) { return pc.n_groups <= simds ? egg_pk_exec_chain_kernel : egg_pk_exec_kernel; }, groups_of, c64,
-                       [](const PackedClass &pc) { return pc.lds_exec; });
+                       [&](const PackedClass &pc) { return pc.lds_exec + (pc.n_groups <= simds ? 64 * 16 : 0); });
         }
     }
     launch_all(EGG_PK_KIND_END, [](const PackedClass &) { return egg_pk_end_kernel; }, tiles_of,

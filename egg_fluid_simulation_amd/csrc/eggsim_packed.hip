@@ -919,12 +919,12 @@ __device__ __forceinline__ void egg_pk_exec_body(const EggPackedArgs &A) {
                 const bool has_pair = (r0 >> 31) != 0;
                 const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
                 double2 pa = lpos[ga], pb = lpos[gb];
-                project_pair_predicated([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
-                                        has_pair, (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], pc[u], overlap, compliance, eps);
-                if (has_pair) {
-                    lpos[ga] = pa;
-                    lpos[gb] = pb;
-                }
+                const bool store = project_pair_predicated(
+                    [&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; }, has_pair,
+                    (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], pc[u], overlap, compliance, eps);
+                // unconditional stores: lanes with nothing to store write their own spare slot behind the particles
+                lpos[store ? ga : np + lane] = pa;
+                lpos[store ? gb : np + lane] = pb;
             } else if (r0 >> 31) {
                 const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
                 double2 pa = lpos[ga], pb = lpos[gb];

@@ -304,8 +304,10 @@ __device__ __forceinline__ void project_pair(SameBatch same_batch, bool slow, do
 // hold (no traps; garbage stays in the lane), the results are taken by select where the reference would have taken
 // them, and only the rare pairs outside the arithmetic window (or flagged slow) branch, afterwards, into the reference
 // path from the unchanged inputs.  Same operations in the same order as project_pair: same bits.
+// Returns whether pa / pb changed (the caller stores them or not by choosing the ADDRESS: the select of the address
+// needs only `fast`, known halfway down the chain, so neither a data select nor a store branch sits behind the last add).
 template <class SameBatch>
-__device__ __forceinline__ void project_pair_predicated(SameBatch same_batch, bool active, bool slow, double2 &pa, double2 &pb,
+__device__ __forceinline__ bool project_pair_predicated(SameBatch same_batch, bool active, bool slow, double2 &pa, double2 &pb,
                                                         double2 wra, double2 wrb, double2 cached, double overlap,
                                                         double compliance, double eps) {
     const double dx = pb.x - pa.x, dy = pb.y - pa.y;
@@ -328,18 +330,16 @@ __device__ __forceinline__ void project_pair_predicated(SameBatch same_batch, bo
     const double tx = nx * correction, ty = ny * correction;
     const double ax = pa.x + -tx * wa, ay = pa.y + -ty * wa;
     const double bx = pb.x + tx * wb, by = pb.y + ty * wb;
-    const bool take = in_range && fast;
     const double2 pa0 = pa, pb0 = pb;
-    pa.x = take ? ax : pa.x;
-    pa.y = take ? ay : pa.y;
-    pb.x = take ? bx : pb.x;
-    pb.y = take ? by : pb.y;
-    if (__builtin_expect(in_range && !fast, 0)) {  // (behind the selects: the common case falls through one untaken branch)
+    pa = make_double2(ax, ay);
+    pb = make_double2(bx, by);
+    if (__builtin_expect(in_range && !fast, 0)) {  // (the common case falls through one untaken branch)
         double2 qa = pa0, qb = pb0;
         project_pair_reference(same_batch, qa, qb, wra, wrb, overlap, compliance, eps);
         pa = qa;
         pb = qb;
     }
+    return in_range;  // out of range: pa / pb hold what the arithmetic made of the inputs, not to be stored
 }
 
 // Hash generations.  The reference clears the cell lists and `collided` only BETWEEN the collision passes

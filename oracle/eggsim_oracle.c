@@ -231,6 +231,7 @@ struct egg_oracle {
     double elapsed, interpolation_alpha;
     double mass_distribution_variance; /* L:447 */
     double max_collision_fraction;     /* L:448 */
+    int64_t budget_n[2]; /* >= 0: the N of max_n_collisions (see egg_oracle_set_budget_particles); -1: the system's own count */
     /* stats */
     egg_oracle_pass_stat *stats;
     int n_stats, cap_stats;
@@ -286,7 +287,10 @@ static void update_environment(egg_oracle *o, psys *s, double sub_delta) { /* L:
     s->env_min_radius = config->min_radius;
     s->env_max_radius = config->max_radius;
 
-    double n = (double)s->n;
+    /* N = every particle of the type in the handler (L:1752-1753).  A test that steps a CHUNK of a larger scene's
+     * independent islands sets N to the whole scene's count, so that the chunk sees the scene's budget. */
+    const int which = (int)(s - o->sys);
+    double n = (double)(o->budget_n[which] >= 0 ? o->budget_n[which] : s->n);
     s->max_n_collisions = o->max_collision_fraction * (n * n); /* L:1752-1753 */
 
     double max_factor = fmax(config->collision_overlap_factor, config->cohesion_interaction_distance_factor);
@@ -647,6 +651,7 @@ egg_oracle *egg_oracle_create(const egg_oracle_config *white, const egg_oracle_c
     o->sys[1].cfg = yolk ? *yolk : *white;
     o->mass_distribution_variance = 4;
     o->max_collision_fraction = 0.05;
+    o->budget_n[0] = o->budget_n[1] = -1;
     o->current_batch_id = 1;
     egg_oracle_step(o, 0, 1, 1); /* L:562, "step once to init environments" */
     o->total_steps = 0;
@@ -874,6 +879,7 @@ int64_t egg_oracle_total_visited(const egg_oracle *o) { return o->total_visited;
 int64_t egg_oracle_total_steps(const egg_oracle *o) { return o->total_steps; }
 
 void egg_oracle_set_trace(egg_oracle *o, int enabled) { o->trace_on = enabled; }
+void egg_oracle_set_budget_particles(egg_oracle *o, int which, int64_t n) { o->budget_n[which] = n; }
 int64_t egg_oracle_n_trace(const egg_oracle *o) { return o->n_trace; }
 void egg_oracle_trace(const egg_oracle *o, egg_oracle_pair *dst) {
     memcpy(dst, o->trace, sizeof(egg_oracle_pair) * (size_t)o->n_trace);

@@ -105,6 +105,11 @@ void egg_oracle_pass_stats(const egg_oracle *o, egg_oracle_pass_stat *dst);
 int64_t egg_oracle_total_visited(const egg_oracle *o);
 int64_t egg_oracle_total_steps(const egg_oracle *o);
 
+/* Test hook for stepping a CHUNK of a larger scene whose islands are independent: the particle count N of the budget
+ * max_n_collisions = 0.05 N^2 (L:1752-1753) becomes `n` (the whole scene's count of that type) instead of the
+ * handler's own; n < 0 restores the reference's rule. */
+void egg_oracle_set_budget_particles(egg_oracle *o, int which, int64_t n);
+
 /* pair tracing of the most recent _step (off by default) */
 void egg_oracle_set_trace(egg_oracle *o, int enabled);
 int64_t egg_oracle_n_trace(const egg_oracle *o);

@@ -98,6 +98,7 @@ def lib():
         L.egg_oracle_total_steps.restype = C.c_int64
         L.egg_oracle_total_steps.argtypes = [P]
         L.egg_oracle_set_trace.argtypes = [P, C.c_int]
+        L.egg_oracle_set_budget_particles.argtypes = [P, C.c_int, C.c_int64]
         L.egg_oracle_n_trace.restype = C.c_int64
         L.egg_oracle_n_trace.argtypes = [P]
         L.egg_oracle_trace.argtypes = [P, C.c_void_p]
@@ -197,6 +198,10 @@ class Oracle:
     @property
     def total_steps(self):
         return self._L.egg_oracle_total_steps(self._h)
+
+    def set_budget_particles(self, which, n):
+        """N of the collision budget 0.05 N^2 (L:1752-1753) when this oracle holds a chunk of a larger scene"""
+        self._L.egg_oracle_set_budget_particles(self._h, which, int(n))
 
     def set_trace(self, on):
         self._L.egg_oracle_set_trace(self._h, int(bool(on)))

@@ -261,3 +261,42 @@ def test_lua_generator_covers_the_python_generator_cases():
     for api in ("getSupported", "getTextureFormats", "newCanvas", "newMesh", "newShader", "validateShader", "getInfo",
                 "getVersion", "getRendererInfo"):  # what construction and _step call (last row)
         assert api in stub, api
+
+
+def test_chunked_oracle_equals_the_whole_scene(oracle_mod):
+    """What the full-size GPU tests rely on (tests/test_gpu_fullsize.py): separate sites are independent islands, so
+    an oracle holding a chunk of them -- with the whole scene's N in its collision budget (L:1752-1753) -- reproduces
+    exactly those batches' particles.  Config-3 layout (four coincident batches per site) and separate blobs; also
+    the counter-case: WITHOUT the scene's N the yolk budget of a small chunk binds and the chunk diverges."""
+    import bench
+    for overlap, n, per in ((4, 48, 8), (1, 40, 4)):
+        xs, ys, _ = bench.grid_positions(n, overlap=overlap)
+        whole = oracle_mod.Oracle()
+        for k in range(n):
+            whole.add(float(xs[k]), float(ys[k]), 50, 15)
+        parts, bare, bare_cut = [], [], False
+        for lo in range(0, n, per):
+            o, b = oracle_mod.Oracle(), oracle_mod.Oracle()
+            o.set_budget_particles(0, n * 157)
+            o.set_budget_particles(1, n * 15)
+            for k in range(lo, lo + per):
+                o.add(float(xs[k]), float(ys[k]), 50, 15)
+                b.add(float(xs[k]), float(ys[k]), 50, 15)
+            parts.append(o)
+            bare.append(b)
+        for step in range(4):
+            for j in range(n):
+                for o in (whole, parts[j // per], bare[j // per]):
+                    o.set_target_position(j + 1 if o is whole else j % per + 1, float(xs[j]) + 2.0 * step, float(ys[j]) - step)
+            for o in [whole] + parts + bare:
+                o.update(1 / 60)
+            assert all(not s["cut"] for o in [whole] + parts for s in o.pass_stats())
+            bare_cut = bare_cut or any(s["cut"] for b in bare for s in b.pass_stats())
+        for w in (0, 1):
+            for f in ("x", "y", "vx", "vy"):
+                assert np.array_equal(whole.field(w, f), np.concatenate([o.field(w, f) for o in parts])), (overlap, w, f)
+        assert whole.total_visited == sum(o.total_visited for o in parts)
+        assert [whole.get_position(j + 1) for j in range(n)] == [parts[j // per].get_position(j % per + 1) for j in range(n)]
+        if overlap == 1:  # four separate 15-particle yolks: ~4 * 90 visited pairs against 0.05 * 60^2 = 180
+            assert bare_cut
+            assert not np.array_equal(whole.field(1, "x"), np.concatenate([b.field(1, "x") for b in bare]))

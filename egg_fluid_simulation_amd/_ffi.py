@@ -40,6 +40,8 @@ OPT_FORCE_GLOBAL_STATE = 8
 OPT_FUSE_TYPES = 9
 OPT_PACKED = 10
 OPT_GROUP_PARTICLES = 11
+OPT_LEVEL_WALK = 12
+PK_VARIANT_LEVELS_INORDER, PK_VARIANT_LEVELS_OOO, PK_VARIANT_EXEC, PK_VARIANT_EXEC_CHAIN, PK_VARIANT_SORT_LDS, PK_VARIANT_SORT_DIRECT = 1, 2, 4, 8, 16, 32
 
 CONFIG_FIELDS = ["damping", "follow_strength", "cohesion_strength",
                  "cohesion_interaction_distance_factor", "collision_strength",
@@ -72,7 +74,7 @@ class EggStats(C.Structure):
                 ("kernel_ms", C.c_double * 2), ("kernel_ms_sum", C.c_double * 2), ("timed_steps", C.c_int64),
                 ("max_pass_visits", C.c_int64 * 2), ("budget", C.c_double * 2), ("fused_launch", C.c_int64),
                 ("packed", C.c_int64 * 2), ("pk_kernel_ms", (C.c_double * 9) * 2), ("pk_kernel_launches", (C.c_int64 * 9) * 2),
-                ("host_ms", C.c_double * 3), ("max_levels", C.c_int64 * 2)]
+                ("host_ms", C.c_double * 3), ("max_levels", C.c_int64 * 2), ("pk_variants", C.c_int64 * 2)]
 
 
 class EggRenderConfig(C.Structure):  # egg_render_config

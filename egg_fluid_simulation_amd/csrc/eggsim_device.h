@@ -115,7 +115,8 @@ static inline int egg_step_threads(int nmax, int spread) {
 // instead of one fused launch per step.  The particles of the participating tiles are kept in PACKED order
 // (tile after tile, atoms in tile order) in scratch arrays for the duration of a step; a collision pass is
 //   egg_pk_lists   (one workgroup per tile)  cell grid + visit lists in the reference's order -> global memory
-//   egg_pk_levels  (one wave per group)      longest-path level of every pair; pairs sorted by level
+//   egg_pk_levels  (one workgroup per group) longest-path level of every pair (in-order or out-of-order walk)
+//   egg_pk_sort    (one workgroup per group) the group's pairs sorted by level
 //   egg_pk_exec    (one wave per group)      the group's positions in LDS; level by level, 64 pairs at a time
 // A GROUP is a run of consecutive tiles whose particles one wave keeps in LDS.  Pairs of one level share no
 // particle and all their predecessors lie in lower levels, so running the levels in order, each level's
@@ -149,6 +150,7 @@ struct EggPackedArgs {
     // entries self | slow << 15 | other << 16 (tile-local indices) of every particle as `self`, ascending
     uint32_t *lists;
     uint16_t *lvl;             // level of each stream entry
+    uint32_t *rank;            // per stream entry (out-of-order level walk): earlier entries involving the self | the partner << 16
     // per group, `sort_cap` words each: the group's pairs sorted by level (bit 31 set, indices group-local), and its
     // work list of `chunk_cap` words: chunk c = first word | (pairs - 1) << 26, at most 64 pairs of ONE level, levels ascending
     uint32_t *sorted;
@@ -190,15 +192,16 @@ static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int us
     b += egg_align16((size_t)stage_cap * n * 2);  // partners kept by the counting pass
     return b;
 }
-// dynamic LDS of egg_pk_levels: level histogram, last level per particle of the group, one stream window per sub-wave
-static inline size_t egg_pk_levels_lds_bytes(int lev_cap, int group_particles, int wd) {
+// dynamic LDS of egg_pk_levels_mr16 (the in-order walk): level histogram, last level and a stamp word per particle of the
+// group, one stream window per sub-wave of 16 lanes
+static inline size_t egg_pk_levels_mr_lds_bytes(int lev_cap, int group_particles, int threads) {
     return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 2) +
-           egg_align16((size_t)(64 / wd) * EGG_PK_WINDOW * 4);
+           egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(threads / 16) * EGG_PK_WINDOW * 4);
 }
-// the multi-run walk (egg_pk_levels_mr*): also a stamp word per particle; `threads` / wd sub-waves
-static inline size_t egg_pk_levels_mr_lds_bytes(int lev_cap, int group_particles, int wd, int threads) {
-    return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 2) +
-           egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(threads / wd) * EGG_PK_WINDOW * 4);
+// dynamic LDS of egg_pk_levels_ooo (the out-of-order walk): level histogram, (completed pairs | last level) and the
+// ranking pass's entry counter per particle of the group (+ a spare counter per lane)
+static inline size_t egg_pk_levels_ooo_lds_bytes(int lev_cap, int group_particles) {
+    return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(group_particles + 64) * 4);
 }
 
 // ---- headless renderer (eggsim_render.hip) ----

@@ -43,11 +43,9 @@ extern "C" __global__ void egg_pk_begin_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_mid_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_lists_fresh_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_lists_stale_kernel(EggPackedArgs A);
-extern "C" __global__ void egg_pk_levels8_kernel(EggPackedArgs A);
-extern "C" __global__ void egg_pk_levels16_kernel(EggPackedArgs A);
-extern "C" __global__ void egg_pk_levels64_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_levels_mr16_kernel(EggPackedArgs A);
-extern "C" __global__ void egg_pk_levels_mr32_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_levels_ooo_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_probe_lds_order_kernel(int trials, unsigned long long *bad);
 extern "C" __global__ void egg_pk_exec_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_exec_chain_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_sort_kernel(EggPackedArgs A);
@@ -173,8 +171,8 @@ struct PackedClass {
     int group_base = 0;     // first slot in the per-group arrays
     size_t meta_tile_geo = 0, meta_grp_geo = 0;  // offsets (ints) into System::pk_meta
     int max_group_particles = 0;
-    int wd = 8;             // lanes per tile in the level walk
-    int levels_threads = 64; // workgroup of the level walk (the multi-run walk spreads a group's tiles over up to four waves)
+    int levels_ooo = 0;     // the level walk of the class: 0 in order (egg_pk_levels_mr16_kernel), 1 out of order (egg_pk_levels_ooo_kernel)
+    int levels_threads = 64; // workgroup of the level walk (up to four waves per group)
     int lcap = 0, scap = 0;  // visit entries / stream words (entries + one header per particle) a tile may have
     int stage_cap = 0;       // partners per particle the list kernel's counting pass keeps in LDS
     int sort_cap = 0;        // words of a group's sorted list
@@ -248,7 +246,7 @@ struct System {  // one particle type
     std::vector<int32_t> pk_meta_host;       // tile_p0 / grp_tile0 of every packed class
     DevBuf<int32_t> pk_meta, pk_src, pk_atom, pk_tile, pk_nchunks;
     DevBuf<double> pk_pos, pk_prev, pk_wr;
-    DevBuf<uint32_t> pk_ckey, pk_lists, pk_sorted, pk_levstart, pk_chunks;
+    DevBuf<uint32_t> pk_ckey, pk_lists, pk_rank, pk_sorted, pk_levstart, pk_chunks;
     size_t pk_chunk_words = 0;
     DevBuf<uint16_t> pk_lvl, pk_aslot;
     size_t pk_meta_claims = 0;               // offset (ints) of the tile claims inside pk_meta
@@ -293,8 +291,8 @@ struct egg_handle {
     int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
     int opt_spin_sleep = -1;  // -1 auto
     bool packed_auto = false;  // the automatic choice, made when the white tiles are formed
-    int opt_levels_wd = 0;    // developer override of the multi-run walk's sub-wave width (16 or 32; 0 = by tile size)
-    int opt_levels_mr = 1;    // packed pipeline: the level walk takes several runs per turn (0: one run per turn; A/B testing)
+    int opt_level_walk = 0;   // packed pipeline, EGG_OPT_LEVEL_WALK: 0 by regime, 1 always in order, 2 out of order wherever the probe allows
+    bool lds_lane_ordered = false;  // one ds_add_rtn serves same-address lanes in ascending lane order (probed at create)
     int opt_packed = -1;      // packed pipeline: -1 automatic (large scenes), 0 never, 1 every eligible class
     int opt_group_particles = 0;  // particles one wave of the packed executor keeps in LDS (16 B each): 0 = by scene size (retile), at most 1280
     int opt_force_global_state = 0;  // test hook: run every tile through the global-memory-state kernel  // threads per particle in the step kernel's workgroups (pair dataflow spreading)
@@ -1031,15 +1029,18 @@ int retile(egg_handle *h, int which) {
                 max_tiles_in_group = std::max(max_tiles_in_group, t_end - t);
                 t = t_end;
             }
-            const int per_group = (lc.n_tiles + pc.n_groups - 1) / pc.n_groups;
-            if (h->opt_levels_mr) {
-                pc.wd = h->opt_levels_wd ? h->opt_levels_wd : 16;  // (32 lanes per tile gained nothing on dense islands)
-                pc.levels_threads = std::min(256, (max_tiles_in_group * pc.wd + 63) / 64 * 64);
-                pc.lds_levels = egg_pk_levels_mr_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd, pc.levels_threads);
+            // The level walk.  While the class's groups are no more than the SIMDs, the step waits for the longest
+            // dependency chain of one group: the out-of-order walk (four waves per group level whatever runs are ready;
+            // a dense island's 6,500 pairs: ~150 turns instead of ~540).  On a full chip the in-order walk's fewer
+            // instructions per pair win.
+            const int simds = 4 * std::max(1, h->prop.multiProcessorCount);
+            pc.levels_ooo = h->lds_lane_ordered && h->opt_level_walk != 1 && (h->opt_level_walk == 2 || pc.n_groups <= simds);
+            if (pc.levels_ooo) {
+                pc.levels_threads = 64 * std::min(16, std::max(4, max_tiles_in_group));  // a wave per tile, at least four per group
+                pc.lds_levels = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles);
             } else {
-                pc.wd = per_group >= 8 ? 8 : 16;
-                pc.levels_threads = 64;
-                pc.lds_levels = egg_pk_levels_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.wd);
+                pc.levels_threads = std::min(256, (max_tiles_in_group * 16 + 63) / 64 * 64);
+                pc.lds_levels = egg_pk_levels_mr_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.levels_threads);
             }
             const size_t sort_words = (size_t)max_tiles_in_group * (size_t)pc.scap + 64;
             pc.chunk_cap = (int)std::min<size_t>(sort_words / 64 + (size_t)s.pk_lev_cap + 8, (size_t)1 << 28);
@@ -1082,6 +1083,9 @@ int retile(egg_handle *h, int which) {
             HIP_TRY(h, s.pk_ckey.reserve(2 * np, false, s.stream));
             HIP_TRY(h, s.pk_lists.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_lvl.reserve(s.pk_entries + 64, false, s.stream));
+            bool any_ooo = false;
+            for (const PackedClass &pc : s.pk) any_ooo |= pc.levels_ooo != 0;
+            if (any_ooo) HIP_TRY(h, s.pk_rank.reserve(s.pk_entries + 64, false, s.stream));
             HIP_TRY(h, s.pk_sorted.reserve(s.pk_sort_words + 64, false, s.stream));
             HIP_TRY(h, s.pk_chunks.reserve(s.pk_chunk_words + 64, false, s.stream));
             HIP_TRY(h, s.pk_nchunks.reserve(2 * ng + 8, false, s.stream));
@@ -1273,6 +1277,7 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.pk_stride = s.pk_n;
     A.lists = s.pk_lists.p + pc.entry_base;
     A.lvl = s.pk_lvl.p + pc.entry_base;
+    A.rank = pc.levels_ooo ? s.pk_rank.p + pc.entry_base : nullptr;
     A.sorted = s.pk_sorted.p + pc.sort_base;
     A.chunks = s.pk_chunks.p + pc.chunk_base;
     A.grp_nchunks = s.pk_nchunks.p + pc.group_base;
@@ -1364,10 +1369,7 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
             launch_all(stale ? EGG_PK_KIND_LISTS_STALE : EGG_PK_KIND_LISTS_FRESH,
                        [&](const PackedClass &) { return stale ? egg_pk_lists_stale_kernel : egg_pk_lists_fresh_kernel; }, tiles_of,
                        [](const PackedClass &pc) { return pc.threads_lists; }, [](const PackedClass &pc) { return pc.lds_lists; });
-            launch_all(EGG_PK_KIND_LEVELS, [&](const PackedClass &pc) {
-                           if (h->opt_levels_mr) return pc.wd == 16 ? egg_pk_levels_mr16_kernel : egg_pk_levels_mr32_kernel;
-                           return pc.wd == 8 ? egg_pk_levels8_kernel : pc.wd == 16 ? egg_pk_levels16_kernel : egg_pk_levels64_kernel;
-                       },
+            launch_all(EGG_PK_KIND_LEVELS, [](const PackedClass &pc) { return pc.levels_ooo ? egg_pk_levels_ooo_kernel : egg_pk_levels_mr16_kernel; },
                        groups_of, [](const PackedClass &pc) { return pc.levels_threads; }, [](const PackedClass &pc) { return pc.lds_levels; });
             launch_all(EGG_PK_KIND_SORT, [](const PackedClass &pc) { return pc.lds_sort ? egg_pk_sort_kernel : egg_pk_sort_direct_kernel; },
                        groups_of, c256,
@@ -1743,6 +1745,7 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
             }
             h->stats.max_pass_visits[w] = most;
             h->stats.max_levels[w] = s.pk.empty() ? 0 : st.max_level;
+            if (getenv("EGGSIM_DEBUG") && !s.pk.empty()) fprintf(stderr, "eggsim: type %d step %lld: walk turns (most of any wave in one pass) %llu, levels %d\n", w, (long long)h->stats.steps, st.rounds, st.max_level);
             h->stats.budget[w] = env[w].budget;
             h->stats.follow_solves += s.n * S;
             s.aabb_on_device = true;  // d_atom_aabb now holds end-of-step cells
@@ -1788,6 +1791,11 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
         for (int w = 0; w < 2; ++w) {
             System &s = h->sys[w];
             h->stats.packed[w] = (int64_t)s.pk.size();
+            h->stats.pk_variants[w] = 0;
+            for (const PackedClass &pc : s.pk)
+                h->stats.pk_variants[w] |= (pc.levels_ooo ? EGG_PK_VARIANT_LEVELS_OOO : EGG_PK_VARIANT_LEVELS_INORDER) |
+                                           (pc.n_groups <= 4 * std::max(1, h->prop.multiProcessorCount) ? EGG_PK_VARIANT_EXEC_CHAIN : EGG_PK_VARIANT_EXEC) |
+                                           (pc.lds_sort ? EGG_PK_VARIANT_SORT_LDS : EGG_PK_VARIANT_SORT_DIRECT);
             for (size_t k = 0; h->opt_timing >= 2 && k < s.pk_stamps_used; ++k) {
                 const System::PkStamp &ps = s.pk_stamps[k];
                 float t = 0;
@@ -1915,10 +1923,9 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
             e = hipFuncSetAttribute((const void *)egg_step_kernel_gl_mg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess)
             for (const void *f : {(const void *)egg_pk_lists_fresh_kernel, (const void *)egg_pk_lists_stale_kernel,
-                                  (const void *)egg_pk_levels8_kernel, (const void *)egg_pk_levels16_kernel,
-                                  (const void *)egg_pk_levels64_kernel, (const void *)egg_pk_exec_kernel, (const void *)egg_pk_exec_chain_kernel,
+                                  (const void *)egg_pk_exec_kernel, (const void *)egg_pk_exec_chain_kernel,
                                   (const void *)egg_pk_sort_kernel, (const void *)egg_pk_levels_mr16_kernel,
-                                  (const void *)egg_pk_levels_mr32_kernel, (const void *)egg_render_splat_kernel})
+                                  (const void *)egg_pk_levels_ooo_kernel, (const void *)egg_render_splat_kernel})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e == hipSuccess) {
             h->lds_limit = want;
@@ -1927,8 +1934,24 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
     }
     (void)hipGetLastError();
     if (const char *e_pk = getenv("EGGSIM_PACKED")) h->opt_packed = atoi(e_pk);  // developer / test override of EGG_OPT_PACKED
-    if (const char *e_mr = getenv("EGGSIM_LEVELS_MR")) h->opt_levels_mr = atoi(e_mr) != 0;
-    if (const char *e_wd = getenv("EGGSIM_LEVELS_WD")) h->opt_levels_wd = atoi(e_wd) == 32 ? 32 : atoi(e_wd) == 16 ? 16 : 0;
+    if (const char *e_lw = getenv("EGGSIM_LEVEL_WALK")) h->opt_level_walk = std::min(2, std::max(0, atoi(e_lw)));  // developer / test override of EGG_OPT_LEVEL_WALK
+    {
+        // egg_pk_levels_ooo_kernel ranks the entries of a pair stream with one LDS atomic add per batch and relies on the
+        // hardware serving same-address lanes of ONE instruction in ascending lane order.  That is what gfx950 does, but
+        // no manual promises it: probe it here (256 workgroups x 64 trials of pseudo-random keys, ~20 us) and use the
+        // in-order walk everywhere if a single lane disagrees.
+        unsigned long long *bad = nullptr, host_bad = ~0ull;
+        if (hipMalloc((void **)&bad, sizeof *bad) == hipSuccess) {
+            if (hipMemset(bad, 0, sizeof *bad) == hipSuccess) {
+                hipLaunchKernelGGL(egg_pk_probe_lds_order_kernel, dim3(256), dim3(64), 0, 0, 64, bad);
+                if (hipMemcpy(&host_bad, bad, sizeof host_bad, hipMemcpyDeviceToHost) != hipSuccess) host_bad = ~0ull;
+            }
+            (void)hipFree(bad);
+        }
+        const hipError_t pe = hipGetLastError();
+        h->lds_lane_ordered = host_bad == 0;
+        if (getenv("EGGSIM_DEBUG")) fprintf(stderr, "eggsim: LDS atomic lane-order probe: %llu mismatches (%s)\n", host_bad, hipGetErrorString(pe));
+    }
     if (const char *e_gp = getenv("EGGSIM_GROUP_PARTICLES")) h->opt_group_particles = std::max(1, atoi(e_gp));
     for (int w = 0; w < 2; ++w) {
         System &s = h->sys[w];
@@ -2979,6 +3002,11 @@ int egg_set_option(egg_handle *h, int option, double value) {
             return EGG_OK;
         case EGG_OPT_PACKED:
             h->opt_packed = value < 0 ? -1 : (value != 0);
+            h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
+            return EGG_OK;
+        case EGG_OPT_LEVEL_WALK:
+            if (!(value == 0 || value == 1 || value == 2)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "level walk must be 0 (by regime), 1 (in order) or 2 (out of order)");
+            h->opt_level_walk = (int)value;
             h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
             return EGG_OK;
         case EGG_OPT_GROUP_PARTICLES:

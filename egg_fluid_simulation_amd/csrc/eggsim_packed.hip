@@ -186,31 +186,7 @@ __device__ __forceinline__ void pk_pre_follow(const EggPackedArgs &A, double2 ps
     out = make_double2(x, y);
 }
 
-// inclusive prefix maximum over the WD consecutive lanes of a sub-wave (sl = lane inside it; WD = 8, 16 or 64), with
-// data-parallel-primitive moves: row_shr inside the rows of 16 lanes (masked where a move would cross into the
-// neighbouring sub-wave), row broadcasts for the whole wave
 #define EGG_NEG_LEVEL (-0x40000000)
-template <int WD>
-__device__ __forceinline__ int subwave_incl_max(int v, int sl) {
-    int t;
-    t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v = max(v, sl >= 1 ? t : EGG_NEG_LEVEL);
-    t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v = max(v, sl >= 2 ? t : EGG_NEG_LEVEL);
-    t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v = max(v, sl >= 4 ? t : EGG_NEG_LEVEL);
-    if (WD > 8) {
-        t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-        v = max(v, (sl & 15) >= 8 ? t : EGG_NEG_LEVEL);
-    }
-    if (WD > 16) {
-        t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-        v = max(v, t);
-        t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-        v = max(v, t);
-    }
-    return v;
-}
 
 }  // namespace
 
@@ -464,111 +440,24 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_fresh_kernel(Egg
 extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_stale_kernel(EggPackedArgs A) { egg_pk_lists_body<true>(A); }
 
 // ------------------------------------------------------------------------------------------------
-// Phase 2: levels.  One wave per group; a sub-wave of WD lanes walks one tile's pair stream.
+// Phase 2: levels.
 //
 // Sequential definition: for the pairs e = (a, b) in the reference's order, level(e) = 1 + max(last[a], last[b]),
 // then last[a] = last[b] = level(e).  A run of one self a (partners b_0 .. b_m-1, all different, none equal to
 // a) gives  l_k = max(l_{k-1}, last[b_k]) + 1  with l_{-1} = last[a], i.e.
-// l_k = k + 1 + max(last[a], max_{j <= k}(last[b_j] - j)): a prefix maximum over the lanes of the sub-wave.
-// The stream is read through a small LDS window per sub-wave (one coalesced refill per EGG_PK_WINDOW words),
-// so the walk itself never waits for global memory.
-template <int WD>
-__device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int g = blockIdx.x;
-    if (g >= A.n_groups) return;
-    const int lane = threadIdx.x;
-    const int4 gg = ((const int4 *)A.grp_geo)[g];
-    const int t0 = __builtin_amdgcn_readfirstlane(gg.x), t1 = __builtin_amdgcn_readfirstlane(gg.y);
-    const int p0 = __builtin_amdgcn_readfirstlane(gg.z), np = __builtin_amdgcn_readfirstlane(gg.w);
+// l_k = k + 1 + max(last[a], max_{j <= k}(last[b_j] - j)): a prefix maximum over the lanes that hold the run.
+
+// End of a level pass (one wave): the deepest level goes to the status block, the level histogram becomes the first
+// slot of every level in the group's sorted list (level 0 is empty) and the executor's work list: chunks of at most
+// 64 pairs, each inside one level, levels ascending.  An overflowed group is left alone by the later phases (the
+// step is re-run with larger tables).
+__device__ __forceinline__ void pk_levels_finish(const EggPackedArgs &A, int g, const uint32_t *hist, int maxlev, bool over, int lane) {
     const int lev_cap = A.lev_cap;
-    constexpr int NSUB = 64 / WD, W = EGG_PK_WINDOW;
-    uint32_t *hist = (uint32_t *)smem;  // [lev_cap + 2] pairs per level
-    uint16_t *last = (uint16_t *)(smem + egg_align16((size_t)(lev_cap + 2) * 4));  // [np] level of each particle's last pair
-    uint32_t *win_all = (uint32_t *)(smem + egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)np * 2));
-    for (int i = lane; i <= lev_cap + 1; i += 64) hist[i] = 0;
-    for (int i = lane; i < np; i += 64) last[i] = 0;
-    // (one wave: its LDS operations execute in issue order, no barrier needed)
-    const int sub = lane / WD, sl = lane % WD;
-    uint32_t *win = win_all + sub * W;
-    int maxlev = 0;
-    bool over = false;
-    for (int ti = t0 + sub; ti < t1; ti += NSUB) {
-        const int base = ((const int4 *)A.tile_geo)[2 * ti].x - p0;
-        const int slen = A.tile_total[ti];
-        const uint32_t *stream = A.lists + (size_t)ti * A.scap;
-        uint16_t *lv = A.lvl + (size_t)ti * A.scap;
-        // One turn = the next (at most WD) entries of ONE self: the entries of a self are contiguous and carry it, so
-        // the run's length inside the window is found with a ballot; last[self] is re-read from LDS every turn, which
-        // also chains the pieces of a run longer than WD.  No branch depends on the run structure.
-        // The window is refilled from registers: the words any next window can need ([q + W - WD, q + 2 W)) are
-        // requested as soon as a window is in place, a whole window's walk ahead of their use.
-        constexpr int PF = (W + WD) / WD;
-        uint32_t pf[PF];
-        int pf_base = 0;
-#pragma unroll
-        for (int u = 0; u < PF; ++u) pf[u] = stream[min(sl + WD * u, max(slen - 1, 0))];
-        int q = 0, wlen = 0, r = 0;
-        while (q + r < slen) {
-            if (r + WD > wlen && q + wlen < slen) {  // fewer than WD entries left in the window and more in the stream
-                q += r;
-                r = 0;
-                wlen = min(W, slen - q);
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int pos = pf_base + sl + WD * u - q;
-                    if (pos >= 0 && pos < W) win[pos] = pf[u];
-                }
-                pf_base = q + W - WD;
-#pragma unroll
-                for (int u = 0; u < PF; ++u) pf[u] = stream[min(pf_base + sl + WD * u, slen - 1)];
-            }
-            const int avail = wlen - r;  // >= 1
-            const uint32_t rec = (sl < avail) ? win[r + sl] : 0u;
-            const uint32_t a0 = win[r] & 0x7FFFu;
-            const int b = (int)((rec >> 16) & 0x7FFFu);
-            // both level reads go out together, before the run length is known (lanes beyond the run read the level
-            // of some other pair's partner and drop it)
-            const int c_raw = (int)last[base + b];
-            const int xa = (int)last[base + (int)a0];
-            // m = entries of this turn: the leading lanes whose self is a0
-            const unsigned long long differs = __ballot((rec & 0x7FFFu) != a0 || sl >= avail);
-            int m;
-            if (WD == 64) {
-                m = differs ? (int)__builtin_ctzll(differs) : 64;
-            } else {
-                const uint32_t mine = (uint32_t)(differs >> (sub * WD)) & ((1u << (WD & 31)) - 1u);
-                m = mine ? (int)__builtin_ctz(mine) : WD;
-            }
-            const bool valid = sl < m;
-            const int d = valid ? c_raw - sl : EGG_NEG_LEVEL;
-            const int pm = subwave_incl_max<WD>(d, sl);
-            int l = sl + 1 + max(xa, pm);
-            if (valid && l > lev_cap) {  // deeper than the level table: report what is needed, keep the tables in range
-                over = true;
-                maxlev = max(maxlev, l);
-                l = lev_cap;
-            }
-            if (valid) {
-                last[base + b] = (uint16_t)l;
-                lv[q + r + sl] = (uint16_t)l;
-                atomicAdd(&hist[l], 1u);
-                maxlev = max(maxlev, l);
-                if (sl == m - 1) last[base + (int)a0] = (uint16_t)l;
-            }
-            r += m;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) maxlev = max(maxlev, __shfl_xor(maxlev, d, 64));
-    over = __any(over);
     if (over && lane == 0) atomicExch(&A.status->fail_levels, 1);
     // the deepest chain of the step (egg_stats.max_levels); most groups see a value that is already larger
     if (lane == 0 && maxlev > __hip_atomic_load(&A.status->max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(&A.status->max_level, maxlev);
     const int nlev = min(maxlev, lev_cap);
-    // first slot of every level in the group's sorted list (level 0 is empty), and the executor's work list: chunks of
-    // at most 64 pairs, each inside one level, levels ascending
     uint32_t *lstart = A.lev_start + (size_t)g * (lev_cap + 2);
     uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
     uint32_t carry = 0, ccarry = 0;
@@ -586,7 +475,6 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         ccarry += (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
     }
-    // an overflowed group is left alone by the later phases (the step is re-run with larger tables)
     const bool usable = !over && ccarry <= (uint32_t)A.chunk_cap && carry <= (uint32_t)A.sort_cap;
     if (lane == 0) {
         lstart[nlev + 1] = carry;
@@ -594,21 +482,19 @@ __device__ __forceinline__ void egg_pk_levels_body(const EggPackedArgs &A) {
         A.grp_nlev[g] = usable ? nlev : 0;
     }
 }
-extern "C" __global__ void __launch_bounds__(64) egg_pk_levels8_kernel(EggPackedArgs A) { egg_pk_levels_body<8>(A); }
-extern "C" __global__ void __launch_bounds__(64) egg_pk_levels16_kernel(EggPackedArgs A) { egg_pk_levels_body<16>(A); }
-extern "C" __global__ void __launch_bounds__(64) egg_pk_levels64_kernel(EggPackedArgs A) { egg_pk_levels_body<64>(A); }
 
-// The same walk, several runs per turn.  A turn takes the next WD entries whatever selves they belong to; runs of
-// different selves may be levelled side by side when they touch no common particle, which is found out on the spot:
-// every entry stamps its two particles with the index of its run inside the turn (LDS minimum: the earliest run
-// wins), reads the stamps back, and a run that finds an earlier run's stamp on one of its particles ends the turn
-// in front of it (the first run never conflicts, so every turn makes progress).  The particles of consecutive selves
-// are rarely the same -- neighbours in index are not neighbours in space (the batches are Fibonacci spirals) -- so
-// a turn carries two to four runs, and the walk needs that many fewer turns.  Inside a turn each run is a segment
-// of the prefix-maximum scan.  One workgroup per group, one sub-wave per tile at a time.
-template <int WD>
-__device__ __forceinline__ void egg_pk_levels_mr_body(const EggPackedArgs &A) {
-    static_assert(WD == 16 || WD == 32, "segments are scanned inside rows of 16 lanes plus one cross-row step");
+// The in-order walk (throughput regime: more groups than SIMDs, every instruction counts).  One workgroup per group,
+// a sub-wave of 16 lanes per tile at a time; the stream is read through a small LDS window per sub-wave (one coalesced
+// refill per EGG_PK_WINDOW words), so the walk itself never waits for global memory.  A turn takes the next 16 entries
+// whatever selves they belong to; runs of different selves may be levelled side by side when they touch no common
+// particle, which is found out on the spot: every entry stamps its two particles with the index of its run inside the
+// turn (LDS minimum: the earliest run wins), reads the stamps back, and a run that finds an earlier run's stamp on one
+// of its particles ends the turn in front of it (the first run never conflicts, so every turn makes progress).  The
+// particles of consecutive selves are rarely the same -- neighbours in index are not neighbours in space (the batches
+// are Fibonacci spirals) -- so a turn carries two to four runs.  Inside a turn each run is a segment of the
+// prefix-maximum scan.
+extern "C" __global__ void __launch_bounds__(256) egg_pk_levels_mr16_kernel(EggPackedArgs A) {
+    constexpr int WD = 16;
     extern __shared__ __align__(16) unsigned char smem[];
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
@@ -642,6 +528,8 @@ __device__ __forceinline__ void egg_pk_levels_mr_body(const EggPackedArgs &A) {
         const int slen = A.tile_total[ti];
         const uint32_t *stream = A.lists + (size_t)ti * A.scap;
         uint16_t *lv = A.lvl + (size_t)ti * A.scap;
+        // The window is refilled from registers: the words any next window can need ([q + W - WD, q + 2 W)) are
+        // requested as soon as a window is in place, a whole window's walk ahead of their use.
         constexpr int PF = (W + WD) / WD;
         uint32_t pf[PF];
         int pf_base = 0;
@@ -668,10 +556,9 @@ __device__ __forceinline__ void egg_pk_levels_mr_body(const EggPackedArgs &A) {
             const int a = (int)(rec & 0x7FFFu), b = (int)((rec >> 16) & 0x7FFFu);
             // run structure of the turn: a run starts where the self changes
             const int a_prev = __builtin_amdgcn_update_dpp(-1, a, 0x111, 0xf, 0xf, false);  // row_shr:1
-            const int a_before = (WD == 32 && (sl & 15) == 0 && sl > 0) ? __shfl_up(a, 1, WD) : a_prev;
-            const bool head = have && (sl == 0 || a != a_before);
+            const bool head = have && (sl == 0 || a != a_prev);
             const unsigned long long heads64 = __ballot(head);
-            const uint32_t heads = (uint32_t)(heads64 >> (sub * WD)) & (WD == 32 ? 0xFFFFFFFFu : 0xFFFFu);
+            const uint32_t heads = (uint32_t)(heads64 >> (sub * WD)) & 0xFFFFu;
             const uint32_t upto = heads & (0xFFFFFFFFu >> (31 - sl));          // heads at lanes <= sl
             const int run_idx = __builtin_popcount(upto) - 1;
             const int run_start = 31 - __builtin_clz(upto | 1u);
@@ -690,7 +577,7 @@ __device__ __forceinline__ void egg_pk_levels_mr_body(const EggPackedArgs &A) {
             }
             const bool clash = have && (sb < (uint32_t)run_idx || sa < (uint32_t)run_idx);
             const unsigned long long clash64 = __ballot(clash);
-            const uint32_t clashes = (uint32_t)(clash64 >> (sub * WD)) & (WD == 32 ? 0xFFFFFFFFu : 0xFFFFu);
+            const uint32_t clashes = (uint32_t)(clash64 >> (sub * WD)) & 0xFFFFu;
             // the turn ends in front of the first run that clashes with an earlier one
             int m = avail;
             if (clashes) {
@@ -710,12 +597,6 @@ __device__ __forceinline__ void egg_pk_levels_mr_body(const EggPackedArgs &A) {
                 if (pos_in_run >= 4 && (sl & 15) >= 4) v = max(v, t);
                 t = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x118, 0xf, 0xf, false);  // row_shr:8
                 if (pos_in_run >= 8 && (sl & 15) >= 8) v = max(v, t);
-            }
-            if (WD == 32) {  // the part of a run that lies in the previous row of 16: its maximum is in that row's last lane
-                const int carry = __shfl(v, 15, WD);
-                if (sl >= 16 && pos_in_run > (sl & 15)) v = max(v, carry);
-                // (lane 15 holds the maximum over its own run's lanes in row 0; a run crossing the row boundary is the
-                // run of lane 15, so the carry belongs to exactly the lanes whose run started before lane 16)
             }
             int l = pos_in_run + 1 + max(xa, v);
             if (valid && l > lev_cap) {  // deeper than the level table: report what is needed, keep the tables in range
@@ -747,37 +628,223 @@ __device__ __forceinline__ void egg_pk_levels_mr_body(const EggPackedArgs &A) {
         maxlev = max(maxlev, wave_max[w]);
         over = over || wave_over[w];
     }
-    if (over && lane == 0) atomicExch(&A.status->fail_levels, 1);
-    if (lane == 0 && maxlev > __hip_atomic_load(&A.status->max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(&A.status->max_level, maxlev);
-    const int nlev = min(maxlev, lev_cap);
-    uint32_t *lstart = A.lev_start + (size_t)g * (lev_cap + 2);
-    uint32_t *chunks = A.chunks + (size_t)g * A.chunk_cap;
-    uint32_t carry = 0, ccarry = 0;
-    for (int b0 = 1; b0 <= nlev; b0 += 64) {
-        const int L = b0 + lane;
-        const uint32_t v = (L <= nlev) ? hist[L] : 0u;
-        const uint32_t nch = (v + 63u) >> 6;
-        const uint32_t incl = (uint32_t)wave_incl_scan((int)v, lane), cincl = (uint32_t)wave_incl_scan((int)nch, lane);
-        const uint32_t start = carry + incl - v, cb = ccarry + cincl - nch;
-        if (L <= nlev) {
-            lstart[L] = start;
-            for (uint32_t c = 0; c < nch; ++c)
-                if (cb + c < (uint32_t)A.chunk_cap) chunks[cb + c] = (start + 64u * c) | ((min(64u, v - 64u * c) - 1u) << 26);
-        }
-        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        ccarry += (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
-    }
-    const bool usable = !over && ccarry <= (uint32_t)A.chunk_cap && carry <= (uint32_t)A.sort_cap;
-    if (lane == 0) {
-        lstart[nlev + 1] = carry;
-        A.grp_nchunks[g] = usable ? (int)ccarry : 0;
-        A.grp_nlev[g] = usable ? nlev : 0;
-    }
+    pk_levels_finish(A, g, hist, maxlev, over, lane);
 }
-extern "C" __global__ void __launch_bounds__(256) egg_pk_levels_mr16_kernel(EggPackedArgs A) { egg_pk_levels_mr_body<16>(A); }
-extern "C" __global__ void __launch_bounds__(256) egg_pk_levels_mr32_kernel(EggPackedArgs A) { egg_pk_levels_mr_body<32>(A); }
 
+// The out-of-order walk (latency regime: no more groups than SIMDs, the chip waits for the longest chain).
+//
+// The in-order walk above is serial per tile: a dense 628-particle island with 6,500 pairs takes ~540 turns.  Here the
+// stream is cut into BATCHES of 64 entries (four rows of 16 lanes); the waves of the workgroup take the batches round
+// robin and level the runs of a batch in WHATEVER order their inputs become final.  That needs, per entry, the
+// number of earlier stream entries that involve its self and its partner (`expect`): an entry may be levelled exactly
+// when the completed-pair counters of both particles have reached those numbers.  In reference order the pairs of a
+// particle p are [p visited by selves < p] [p's own run] [p visited by selves > p (stale passes only)], so three LDS
+// atomic adds per batch, issued by ONE wave in stream order, hand out the numbers: partners larger than the self,
+// selves, partners smaller than the self.  Inside one ds_add_rtn_u32 the lanes that hit the same address are served in
+// ascending lane order on gfx950 (not an architectural promise: egg_pk_probe_lds_order_kernel checks it when a handle is
+// created, and the host only chooses this kernel where it holds), which is the stream order of a batch.
+//   word[p] = completed pairs of p << 16 | level of its last pair     (one 32-bit word: read and written whole)
+// A run (or the piece of it inside a row) whose first pending entry finds word[self] at its expected count levels the
+// longest prefix whose partners are at theirs -- the same prefix-maximum formula as above -- and publishes the new
+// words; other waves see them on their next poll.  Deadlock-free: the oldest unfinished entry of the stream depends
+// only on finished ones.
+extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggPackedArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int g = blockIdx.x;
+    if (g >= A.n_groups) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int4 gg = ((const int4 *)A.grp_geo)[g];
+    const int t0 = __builtin_amdgcn_readfirstlane(gg.x), t1 = __builtin_amdgcn_readfirstlane(gg.y);
+    const int p0 = __builtin_amdgcn_readfirstlane(gg.z), np = __builtin_amdgcn_readfirstlane(gg.w);
+    const int nt = t1 - t0;  // <= 64 tiles per group
+    const int lev_cap = A.lev_cap;
+    uint32_t *hist = (uint32_t *)smem;  // [lev_cap + 2] pairs per level
+    unsigned char *q8 = smem + egg_align16((size_t)(lev_cap + 2) * 4);
+    uint32_t *word = (uint32_t *)q8;  // [np]
+    q8 += egg_align16((size_t)np * 4);
+    uint32_t *cnt = (uint32_t *)q8;   // [np] entries seen so far per particle (the ranking pass)
+    __shared__ int tile_base[64], tile_len[64];
+    __shared__ int wave_max[16], wave_over[16];
+    for (int i = tid; i <= lev_cap + 1; i += nthreads) hist[i] = 0;
+    for (int i = tid; i < np + 64; i += nthreads) {  // (64 spare counters behind the particles: see the ranking pass)
+        if (i < np) word[i] = 0;
+        cnt[i] = 0;
+    }
+    if (tid < nt) {  // the group's tiles: first particle (group-local), stream length
+        tile_base[tid] = ((const int4 *)A.tile_geo)[2 * (t0 + tid)].x - p0;
+        tile_len[tid] = A.tile_total[t0 + tid];
+    }
+    __syncthreads();
+    // ---- ranking: one wave per tile, stream order.  expect(self) | expect(partner) << 16 per entry, into A.rank.
+    // Every lane takes part in all three adds (a branch around an atomic costs a wait for its result): a lane whose
+    // add does not apply adds 0 to a spare counter of its own.
+    for (int t = wave; t < nt; t += nwaves) {
+        const int base = tile_base[t], slen = tile_len[t];
+        const uint32_t *stream = A.lists + (size_t)(t0 + t) * A.scap;
+        uint32_t *rank = A.rank + (size_t)(t0 + t) * A.scap;
+        const int spare = np + lane;
+        uint32_t nxt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = stream[min(64 * u + lane, max(slen - 1, 0))];
+        for (int e0 = 0; e0 < slen; e0 += 256) {
+            uint32_t rec[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rec[u] = nxt[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[u] = stream[min(e0 + 256 + 64 * u + lane, slen - 1)];  // (the next four batches are on their way)
+            uint32_t xs[4], xo[4];  // (all twelve adds go out before the first result is waited for)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool valid = e0 + 64 * u + lane < slen;
+                const int a = (int)(rec[u] & 0x7FFFu), b = (int)((rec[u] >> 16) & 0x7FFFu);
+                const bool up = valid && b > a, down = valid && b < a;
+                const uint32_t x1 = __hip_atomic_fetch_add(&cnt[up ? base + b : spare], up ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __asm__ volatile("" ::: "memory");
+                xs[u] = __hip_atomic_fetch_add(&cnt[valid ? base + a : spare], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __asm__ volatile("" ::: "memory");
+                const uint32_t x3 = __hip_atomic_fetch_add(&cnt[down ? base + b : spare], down ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __asm__ volatile("" ::: "memory");
+                xo[u] = up ? x1 : x3;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 64 * u + lane;
+                if (e < slen) rank[e] = (xs[u] & 0xFFFFu) | (xo[u] << 16);
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the walk.  Fewer tiles than waves: the waves of a tile take its batches round robin; otherwise a wave
+    // walks whole tiles alone.
+    int maxlev = 0;
+    unsigned int turns = 0;
+    bool over = false;
+    const int sl = lane & 15, row = lane >> 4;
+    const int wpt = max(1, nwaves / nt), conc = min(nt, nwaves);  // waves per tile, tiles walked side by side
+    const int sub = wave / conc;
+    for (int t = wave % conc; t < nt && sub < wpt; t += conc) {
+        const int base = tile_base[t], slen = tile_len[t];
+        const uint32_t *stream = A.lists + (size_t)(t0 + t) * A.scap;
+        const uint32_t *rank = A.rank + (size_t)(t0 + t) * A.scap;
+        uint16_t *lv = A.lvl + (size_t)(t0 + t) * A.scap;
+        const int nb = (slen + 63) >> 6;
+        uint32_t n_rec = 0, n_rk = 0;
+        if (sub < nb) {
+            n_rec = stream[min(sub * 64 + lane, slen - 1)];
+            n_rk = rank[min(sub * 64 + lane, slen - 1)];
+        }
+        for (int q = sub; q < nb; q += wpt) {
+            const uint32_t rec = n_rec, rk = n_rk;
+            const int e = q * 64 + lane;
+            if (q + wpt < nb) {  // the next batch of this wave is requested before this one is walked
+                n_rec = stream[min(e + wpt * 64, slen - 1)];
+                n_rk = rank[min(e + wpt * 64, slen - 1)];
+            }
+            const bool valid = e < slen;
+            const int a = base + (int)(rec & 0x7FFFu), b = base + (int)((rec >> 16) & 0x7FFFu);
+            const uint32_t ea = rk & 0xFFFFu, eb = rk >> 16;
+            // run pieces inside the row of 16 lanes
+            const int a_prev = __builtin_amdgcn_update_dpp(-1, a, 0x111, 0xf, 0xf, false);  // row_shr:1
+            const bool head = valid && (sl == 0 || a != a_prev);
+            const uint32_t heads = (uint32_t)(__ballot(head) >> (row * 16)) & 0xFFFFu;
+            const uint32_t upto = heads & (0xFFFFu >> (15 - sl));  // heads at lanes <= sl
+            const int seg_start = 31 - __builtin_clz(upto | 1u);
+            const uint32_t above = heads >> (sl + 1);
+            const uint32_t seg_end = above ? (uint32_t)(sl + 1 + __builtin_ctz(above)) : 16u;
+            const uint32_t segmask = valid ? (0xFFFFu >> (16u - seg_end)) & ~((1u << seg_start) - 1u) : 0u;
+            // f: the first lane of my piece that is not levelled yet (the pending lanes are its tail [f, seg_end)); the
+            // expected counts of a piece's lanes are consecutive, so every lane knows the count its piece is waiting for
+            uint32_t f = valid ? (uint32_t)seg_start : 17u;
+            const uint32_t eas = ea - (uint32_t)sl;                   // + f: what word[self] must hold for lane f to go
+            const uint32_t ebp = (eb + 1u) << 16, eap = (ea + 1u) << 16;  // the counts this entry leaves behind
+            uint16_t *lve = lv + e;
+            while (__any(valid && (uint32_t)sl >= f && f < seg_end)) {
+                ++turns;
+                const uint32_t wa = __hip_atomic_load(&word[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t wb = __hip_atomic_load(&word[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t R = (uint32_t)(__ballot((wb >> 16) == eb) >> (row * 16));  // lanes of my row whose partner is ready
+                const uint32_t nr = segmask & ~R & ~((1u << f) - 1u);
+                const uint32_t stop = min((nr ? (uint32_t)__builtin_ctz(nr) : 0xFFFFFFFFu), seg_end);
+                const bool ok = (wa >> 16) == eas + f;
+                const uint32_t pos = (uint32_t)sl - f;
+                const bool fire = valid && ok && pos < stop - f;
+                if (!__any(fire)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                int v = fire ? (int)(wb & 0xFFFFu) - (int)pos : EGG_NEG_LEVEL;
+                {
+                    int tt;
+                    tt = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+                    if (fire && pos >= 1u) v = max(v, tt);
+                    tt = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+                    if (fire && pos >= 2u) v = max(v, tt);
+                    tt = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+                    if (fire && pos >= 4u) v = max(v, tt);
+                    tt = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+                    if (fire && pos >= 8u) v = max(v, tt);
+                }
+                if (fire) {
+                    const int lraw = (int)pos + 1 + max((int)(wa & 0xFFFFu), v);
+                    maxlev = max(maxlev, lraw);  // deeper than the level table: reported below, the tables stay in range
+                    const uint32_t l = (uint32_t)min(lraw, lev_cap);
+                    __hip_atomic_store(&word[b], ebp | l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((uint32_t)sl == stop - 1u) __hip_atomic_store(&word[a], eap | l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    *lve = (uint16_t)l;
+                    atomicAdd(&hist[l], 1u);
+                }
+                f = (ok && f < stop) ? stop : f;
+            }
+        }
+    }
+    over = maxlev > lev_cap;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxlev = max(maxlev, __shfl_xor(maxlev, d, 64));
+    over = __any(over);
+    if (lane == 0) {
+        wave_max[wave] = maxlev;
+        wave_over[wave] = over ? 1 : 0;
+        atomicMax(&A.status->rounds, (unsigned long long)turns);  // (diagnostic: the most turns any wave of the step's walks took)
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    for (int w = 0; w < nwaves; ++w) {
+        maxlev = max(maxlev, wave_max[w]);
+        over = over || wave_over[w];
+    }
+    pk_levels_finish(A, g, hist, maxlev, over, lane);
+}
+
+// Does one ds_add_rtn_u32 serve the lanes that hit the same LDS address in ascending lane order?  (What
+// egg_pk_levels_ooo_kernel's ranking pass relies on.)  Pseudo-random keys from key spaces of 1 .. 1000 values; every
+// mismatch against the exact count of earlier lanes with the same key is counted.
+extern "C" __global__ void __launch_bounds__(64) egg_pk_probe_lds_order_kernel(int trials, unsigned long long *bad) {
+    __shared__ uint32_t cnt[1024];
+    const int lane = threadIdx.x;
+    const int nkeys = 1 + (int)((blockIdx.x * 37u) % 1000u);
+    uint32_t s = 0x9E3779B9u * (blockIdx.x * 64u + lane + 1u);
+    unsigned long long mism = 0;
+    for (int t = 0; t < trials; ++t) {
+        for (int k = lane; k < nkeys; k += 64) cnt[k] = 0;
+        __syncthreads();
+        s = s * 1664525u + 1013904223u;
+        const uint32_t key = (((s >> 8) & 0xFFFFu) * (uint32_t)nkeys) >> 16;  // in [0, nkeys)
+        const uint32_t got = __hip_atomic_fetch_add(&cnt[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t want = 0;
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t kj = (uint32_t)__shfl((int)key, j, 64);
+            want += (j < lane && kj == key) ? 1u : 0u;
+        }
+        mism += got != want ? 1ull : 0ull;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mism += __shfl_xor(mism, d, 64);
+    if (lane == 0 && mism) atomicAdd(bad, mism);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Phase 2b: counting sort of a group's pairs by level (one workgroup per group: the walk above is one wave, this
 // part has no dependencies and wants many loads in flight).  Indices become group-local; bit 31 marks a pair.
 // IN_LDS: the sorted list is assembled in LDS and written out in whole lines (a scatter straight to global memory

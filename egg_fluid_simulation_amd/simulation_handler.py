@@ -553,7 +553,8 @@ class SimulationHandler:
                     kernel_ms=list(s.kernel_ms), kernel_ms_sum=list(s.kernel_ms_sum), timed_steps=s.timed_steps,
                     max_pass_visits=list(s.max_pass_visits), budget=list(s.budget), fused_launch=int(s.fused_launch),
                     packed=list(s.packed), pk_kernel_ms=[list(r) for r in s.pk_kernel_ms],
-                    pk_kernel_launches=[list(r) for r in s.pk_kernel_launches], host_ms=list(s.host_ms), max_levels=list(s.max_levels))
+                    pk_kernel_launches=[list(r) for r in s.pk_kernel_launches], host_ms=list(s.host_ms), max_levels=list(s.max_levels),
+                    pk_variants=list(s.pk_variants))
 
     def selftest_arith(self, n=1 << 24, seed=1):
         """mismatches of the kernel's hand-expanded f64 division against `/` on n random operand pairs"""

@@ -244,6 +244,16 @@ enum {
     EGG_PK_KIND_SORT, EGG_PK_KIND_EXEC, EGG_PK_KIND_END, EGG_PK_KIND_REDUCE, EGG_PK_N_KINDS
 };
 
+/* egg_stats.pk_variants: the kernel a phase of the packed pipeline runs depends on the regime (csrc/eggsim_packed.hip) */
+enum {
+    EGG_PK_VARIANT_LEVELS_INORDER = 1, /* egg_pk_levels_mr16_kernel: more groups than SIMDs */
+    EGG_PK_VARIANT_LEVELS_OOO = 2,     /* egg_pk_levels_ooo_kernel: the step waits for the longest chain of one group */
+    EGG_PK_VARIANT_EXEC = 4,           /* egg_pk_exec_kernel */
+    EGG_PK_VARIANT_EXEC_CHAIN = 8,     /* egg_pk_exec_chain_kernel: branch-free projection, executor waves alone on their SIMDs */
+    EGG_PK_VARIANT_SORT_LDS = 16,      /* egg_pk_sort_kernel: sorted list assembled in LDS */
+    EGG_PK_VARIANT_SORT_DIRECT = 32    /* egg_pk_sort_direct_kernel */
+};
+
 /* counters of the device path, cumulative since creation */
 typedef struct {
     int64_t steps;           /* _step calls executed */
@@ -273,6 +283,8 @@ typedef struct {
     /* packed pipeline: the longest chain of dependent pairs in one collision pass of the most recent _step, per type -- the
      * number of levels its executor ran one after the other (the path's latency floor: DESIGN.md section 4) */
     int64_t max_levels[2];
+    /* packed pipeline: which kernel variants the classes of that type run (EGG_PK_VARIANT_* bits; several classes may differ) */
+    int64_t pk_variants[2];
 } egg_stats;
 int egg_get_stats(egg_handle *h, egg_stats *out);
 
@@ -294,7 +306,8 @@ enum {
     EGG_OPT_FORCE_GLOBAL_STATE,     /* test hook: 1 = every tile keeps its state in global memory (the large-island fallback) */
     EGG_OPT_FUSE_TYPES,             /* 1 (default): white and yolk tiles share one launch when the chip holds several tiles per CU; 0: one launch per type */
     EGG_OPT_PACKED,                 /* packed pipeline (one launch per phase, pair projections of many islands packed into full waves): -1 automatic (large scenes), 0 never, 1 whenever a launch class is eligible */
-    EGG_OPT_GROUP_PARTICLES         /* packed pipeline: particles whose positions one wave of the pair executor keeps in LDS (0, the default: by scene size, 320..1280) */
+    EGG_OPT_GROUP_PARTICLES,        /* packed pipeline: particles whose positions one wave of the pair executor keeps in LDS (0, the default: by scene size, 320..1280) */
+    EGG_OPT_LEVEL_WALK              /* packed pipeline, the pass that gives every pair its dependency level: 0 (default) by regime -- out of order while the groups are no more than the chip's SIMDs, in order on a full chip --, 1 always in order, 2 out of order everywhere */
 };
 int egg_set_option(egg_handle *h, int option, double value);
 

@@ -100,6 +100,8 @@ def test_config3_full_size_every_site_vs_oracle(egg, oracle_mod):
         assert h.update(1 / 60) == 1
     st = h.stats()
     assert st["packed"][WHITE] >= 1, st  # the packed pipeline, chosen by the host itself
+    from egg_fluid_simulation_amd import _ffi
+    assert st["pk_variants"][WHITE] == _ffi.PK_VARIANT_LEVELS_OOO | _ffi.PK_VARIANT_EXEC_CHAIN | _ffi.PK_VARIANT_SORT_DIRECT, st
     assert st["n_tiles"][WHITE] == n // overlap
     _check_budget_not_binding(st)
     # 16 sites per chunk: the yolk type's own 0.05 (16 * 60)^2 would not bind either, but the chunk carries the scene's N anyway
@@ -176,6 +178,8 @@ def _separate_blobs_full(egg, om, side, steps, stride=1):
     st = h.stats()
     assert st["n_tiles"][WHITE] == n and st["redo_steps"] == 0, st
     assert st["packed"][WHITE] >= 1
+    from egg_fluid_simulation_amd import _ffi
+    assert st["pk_variants"][WHITE] & (_ffi.PK_VARIANT_LEVELS_INORDER | _ffi.PK_VARIANT_EXEC), st  # the full-chip variants
     _check_budget_not_binding(st)
     rows = list(range(0, side, stride))
     chunks = [(r * side + c, r * side + c + 64) for r in rows for c in range(0, side, 64)]

@@ -1,5 +1,5 @@
 """Round-2 parity cases of the device path (through the C ABI) against the CPU oracle:
-  * BASELINE configs 4 and 5 at full size on one GPU (sampled-island parity, determinism, tiling);
+  * (BASELINE configs 3, 4 and 5 at full size: tests/test_gpu_fullsize.py, every island against the oracle)
   * the mass guard of the pair loop (simulation_handler.lua:1601) and what `n_collided` counts there;
   * particles closer than math.eps (math.lua:53-56: normalize returns (0, 0));
   * a yolk-only mass change between two fused launches (L:1420-1430, L:1731-1744);
@@ -34,72 +34,6 @@ def _same(h, o, tag):
 def _grid_xy(side, pitch=160.0, x0=100.0):
     k = np.arange(side * side)
     return x0 + pitch * (k % side), x0 + pitch * (k // side)
-
-
-def _full_size_config(egg, oracle_mod, side, steps, n_sample, seed):
-    """`side` x `side` non-overlapping batches (BASELINE config 4: 128, config 5: 256) on ONE GPU.
-    Non-overlapping batches are independent islands and the budget 0.05 N^2 is far from binding, so an
-    oracle that holds only a SAMPLE of the batches, at the same coordinates and in the same order, must
-    reproduce exactly those batches' particles (the sequential oracle cannot run 11 M particles in a test)."""
-    xs, ys = _grid_xy(side)
-    n = side * side
-    rng = np.random.default_rng(seed)
-    sample = np.unique(np.concatenate([[0, side - 1, n - side, n - 1, n // 2 + side // 2],
-                                       rng.choice(n, n_sample, replace=False)]))
-    h = egg.SimulationHandler()
-    ids = h.add_many(xs, ys, 50, 15)
-    o = oracle_mod.Oracle()
-    for k in sample:
-        o.add(float(xs[k]), float(ys[k]), 50, 15)
-    # every target translates by the same small vector per step (the gate-B motion at reduced amplitude:
-    # islands must stay apart at the 160 px pitch)
-    for step in range(steps):
-        dx, dy = 3.0 * (step + 1), -2.0 * (step + 1)
-        h.set_target_positions(ids, xs + dx, ys + dy)
-        for j, k in enumerate(sample):
-            o.set_target_position(j + 1, float(xs[k] + dx), float(ys[k] + dy))
-        assert h.update(1 / 60) == 1
-        o.update(1 / 60)
-    st = h.stats()
-    assert st["n_tiles"][WHITE] == n and st["redo_steps"] == 0, st
-    assert st["single_tile"] == [0, 0]
-    assert h.get_n_particles() == (n * N_W, n * N_Y)
-    state = {}
-    for w, per in ((WHITE, N_W), (YOLK, N_Y)):
-        for f in ("x", "y", "vx", "vy"):
-            dev = h.download(w, f)
-            state[(w, f)] = dev
-            got = dev.reshape(n, per)[sample].ravel()
-            assert np.array_equal(got, o.field(w, f)), (side, w, f)
-    gx, gy = h.get_positions(ids[sample])
-    ref = np.array([o.get_position(j + 1) for j in range(len(sample))])
-    assert np.array_equal(gx, ref[:, 0]) and np.array_equal(gy, ref[:, 1])
-    return h, state, (xs, ys, ids)
-
-
-def test_config4_16384_batches_full_size(egg, oracle_mod):
-    h, state, (xs, ys, _) = _full_size_config(egg, oracle_mod, 128, 3, 16, seed=4)
-    # (islands at different absolute coordinates round differently, so their visit counts differ slightly:
-    # only the order of magnitude is checked here; the sampled islands were compared bit for bit above)
-    per_batch = h.stats()["pair_solves"] / 16384 / 3
-    assert 3000 < per_batch < 6000
-    # determinism: a second handler (16,384 independently scheduled tiles) reproduces every bit
-    h2 = egg.SimulationHandler()
-    ids2 = h2.add_many(xs, ys, 50, 15)
-    for step in range(3):
-        h2.set_target_positions(ids2, xs + 3.0 * (step + 1), ys - 2.0 * (step + 1))
-        h2.update(1 / 60)
-    for (w, f), a in state.items():
-        assert np.array_equal(h2.download(w, f), a), (w, f)
-    assert h2.stats()["pair_solves"] == h.stats()["pair_solves"]
-
-
-def test_config5_65536_batches_full_size(egg, oracle_mod):
-    h, state, _ = _full_size_config(egg, oracle_mod, 256, 2, 16, seed=5)
-    assert h.get_n_particles() == (65536 * N_W, 65536 * N_Y)  # 11,272,192 particles on one GPU
-    # every particle finite and within reach of its batch's target
-    x = state[(WHITE, "x")].reshape(65536, N_W)
-    assert np.isfinite(x).all() and np.isfinite(state[(WHITE, "vy")]).all()
 
 
 MASS_TWEAKS = [
@@ -239,18 +173,30 @@ def test_state_changes_are_refused_while_a_step_is_in_flight(egg, oracle_mod):
 # supports, overlapping / coincident batches, moving targets with re-tiling every step, live config changes, adds and
 # removes, and the fused kernel stepping the same scene (both paths must give the same bits).
 
-def _packed(egg, **kw):
+WALKS = [1, 2]  # EGG_OPT_LEVEL_WALK: the in-order walk (egg_pk_levels_mr16_kernel) and the out-of-order one (egg_pk_levels_ooo_kernel)
+
+
+def _packed(egg, walk=0, **kw):
     from egg_fluid_simulation_amd import _ffi
     h = egg.SimulationHandler(**kw)
     h.set_option(_ffi.OPT_PACKED, 1)
+    h.set_option(_ffi.OPT_LEVEL_WALK, walk)
     return h
 
 
+def _walk_used(h, walk):
+    from egg_fluid_simulation_amd import _ffi
+    v = h.stats()["pk_variants"][WHITE]
+    want = {1: _ffi.PK_VARIANT_LEVELS_INORDER, 2: _ffi.PK_VARIANT_LEVELS_OOO}[walk]
+    return (v & (_ffi.PK_VARIANT_LEVELS_INORDER | _ffi.PK_VARIANT_LEVELS_OOO)) == want
+
+
+@pytest.mark.parametrize("walk", WALKS)
 @pytest.mark.parametrize("name", ["cfg1_moving", "four_batches", "substeps_3_2", "substeps_2_1"])
-def test_packed_pipeline_matches_golden(egg, name):
+def test_packed_pipeline_matches_golden(egg, name, walk):
     from conftest import load_golden, replay_golden
     g = load_golden(name)
-    h = _packed(egg)
+    h = _packed(egg, walk)
 
     def state(hh, w):
         return np.array([hh.download(w, f) for f in ("x", "y", "vx", "vy")])
@@ -261,17 +207,18 @@ def test_packed_pipeline_matches_golden(egg, name):
     replay_golden(g, h, state, check)
     assert h.stats()["pair_solves"] == int(g["visits"].sum())
     # one batch: the yolk budget binds -> that type runs the exact-budget fused tile, the white type the packed pipeline
-    assert h.stats()["packed"][WHITE] >= 1
+    assert h.stats()["packed"][WHITE] >= 1 and _walk_used(h, walk)
 
 
+@pytest.mark.parametrize("walk", WALKS)
 @pytest.mark.parametrize("S,C", [(1, 1), (1, 3), (2, 1), (2, 2), (2, 3), (3, 2), (4, 3)])
-def test_packed_pipeline_substep_and_pass_shapes(egg, oracle_mod, S, C):
+def test_packed_pipeline_substep_and_pass_shapes(egg, oracle_mod, S, C, walk):
     """fresh passes, the stale first pass of every later sub-step (L:1905-1912), one pass per sub-step with two
     sub-steps (two live hash generations); three or more generations fall back to the fused kernel"""
     n = 14
     xs = 100.0 + 95.0 * (np.arange(n) % 5)
     ys = 100.0 + 95.0 * (np.arange(n) // 5)
-    h, o = _packed(egg), oracle_mod.Oracle()
+    h, o = _packed(egg, walk), oracle_mod.Oracle()
     ids = h.add_many(xs, ys, 50, 15)
     for a, b in zip(xs, ys):
         o.add(float(a), float(b), 50, 15)
@@ -284,14 +231,16 @@ def test_packed_pipeline_substep_and_pass_shapes(egg, oracle_mod, S, C):
         o.step(1 / 60, S, C)
         _same(h, o, (S, C, k))
     assert h.stats()["packed"][WHITE] >= 1, h.stats()  # (the blobs merge into one 2198-particle island)
+    assert _walk_used(h, walk)
 
 
-def test_packed_pipeline_dense_and_sparse_islands_with_hand_made_chaos(egg, oracle_mod):
+@pytest.mark.parametrize("walk", WALKS)
+def test_packed_pipeline_dense_and_sparse_islands_with_hand_made_chaos(egg, oracle_mod, walk):
     """coincident batches (dense islands, lists beyond LDS), separate blobs, a blob chasing a teleporting target through
     the others (islands merge and split, claims fail and steps are re-run), a live config change, a remove and an add"""
     from egg_fluid_simulation_amd.default_config import default_configs
     rng = np.random.default_rng(11)
-    h, o = _packed(egg), oracle_mod.Oracle()
+    h, o = _packed(egg, walk), oracle_mod.Oracle()
     centers = [(300.0, 300.0)] * 4 + [(900.0 + 170.0 * (k % 4), 200.0 + 170.0 * (k // 4)) for k in range(12)]
     ids = []
     for x, y in centers:
@@ -319,7 +268,7 @@ def test_packed_pipeline_dense_and_sparse_islands_with_hand_made_chaos(egg, orac
         if step % 5 == 4:
             _same(h, o, step)
     _same(h, o, "end")
-    assert h.stats()["packed"][WHITE] >= 1
+    assert h.stats()["packed"][WHITE] >= 1 and _walk_used(h, walk)
 
 
 def test_packed_and_fused_paths_give_the_same_bits(egg):

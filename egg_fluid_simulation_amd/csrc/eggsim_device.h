@@ -16,6 +16,8 @@ struct EggStatus {
     int32_t was_cut;        // single-tile mode: the collision budget cut some pass (L:1657-1658)
     int32_t fail_levels;    // packed pipeline: a group's pair-dependency DAG is deeper than the level table of the launch
     int32_t max_level;      // deepest level any group reached (what the level table must hold)
+    int32_t fail_levlds;    // packed pipeline, out-of-order walk: a tile's pair stream is longer than the LDS level array of the launch
+    int32_t reserved0;
     unsigned long long visits[EGG_MAX_PASSES]; // visited pairs per collision pass, summed over tiles
     unsigned long long max_list;               // largest visit-list length any tile had in one pass
     unsigned long long rounds;                 // DAG rounds, summed over tiles and passes
@@ -170,6 +172,8 @@ struct EggPackedArgs {
     double sub_delta, damping, follow_compliance, collision_compliance, overlap_factor, cell_size, eps;
     int32_t n_substeps, n_collision_steps;
     int32_t pass_seq, substep, stale;  // of the launch
+    int32_t tune;              // developer experiments (EGGSIM_TUNE), 0 in normal operation
+    int32_t lev_lds_cap;       // out-of-order walk: entries of a tile's stream whose levels fit the LDS array of the launch
     EggStatus *status, *status_next;
 };
 #define EGG_PK_MAX_PASSES 64
@@ -199,9 +203,11 @@ static inline size_t egg_pk_levels_mr_lds_bytes(int lev_cap, int group_particles
            egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(threads / 16) * EGG_PK_WINDOW * 4);
 }
 // dynamic LDS of egg_pk_levels_ooo (the out-of-order walk): level histogram, (completed pairs | last level) and the
-// ranking pass's entry counter per particle of the group (+ a spare counter per lane)
-static inline size_t egg_pk_levels_ooo_lds_bytes(int lev_cap, int group_particles) {
-    return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(group_particles + 64) * 4);
+// ranking pass's entry counter per particle of the group
+// (+ a spare counter per lane), the levels of every stream entry of the group's tiles
+static inline size_t egg_pk_levels_ooo_lds_bytes(int lev_cap, int group_particles, int tiles, int lev_lds_cap) {
+    return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(group_particles + 64) * 4) +
+           egg_align16((size_t)tiles * (size_t)lev_lds_cap * 2);
 }
 
 // ---- headless renderer (eggsim_render.hip) ----

@@ -171,6 +171,7 @@ struct PackedClass {
     int group_base = 0;     // first slot in the per-group arrays
     size_t meta_tile_geo = 0, meta_grp_geo = 0;  // offsets (ints) into System::pk_meta
     int max_group_particles = 0;
+    int lev_lds_cap = 0;    // out-of-order walk: stream entries per tile whose levels the LDS of the launch holds
     int levels_ooo = 0;     // the level walk of the class: 0 in order (egg_pk_levels_mr16_kernel), 1 out of order (egg_pk_levels_ooo_kernel)
     int levels_threads = 64; // workgroup of the level walk (up to four waves per group)
     int lcap = 0, scap = 0;  // visit entries / stream words (entries + one header per particle) a tile may have
@@ -254,6 +255,7 @@ struct System {  // one particle type
     size_t pk_entries = 0;                   // stream words over all packed tiles
     size_t pk_sort_words = 0;                // sorted-list words over all packed groups
     int pk_lev_cap = 255;                    // levels the tables hold; grows when a group's DAG is deeper
+    size_t pk_lev_lds_min = 0;               // out-of-order walk: smallest LDS level array (entries per tile) after a fail_levlds
     bool pk_plan_dirty = true;
     // EGG_OPT_TIMING = 2: one event pair per launch group of the packed pipeline, read back when the step is committed
     struct PkStamp { hipEvent_t a, b; int kind, launches; };
@@ -291,6 +293,7 @@ struct egg_handle {
     int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
     int opt_spin_sleep = -1;  // -1 auto
     bool packed_auto = false;  // the automatic choice, made when the white tiles are formed
+    int opt_tune = 0;         // EGGSIM_TUNE: developer experiments inside the packed kernels
     int opt_level_walk = 0;   // packed pipeline, EGG_OPT_LEVEL_WALK: 0 by regime, 1 always in order, 2 out of order wherever the probe allows
     bool lds_lane_ordered = false;  // one ds_add_rtn serves same-address lanes in ascending lane order (probed at create)
     int opt_packed = -1;      // packed pipeline: -1 automatic (large scenes), 0 never, 1 every eligible class
@@ -1036,9 +1039,15 @@ int retile(egg_handle *h, int which) {
             const int simds = 4 * std::max(1, h->prop.multiProcessorCount);
             pc.levels_ooo = h->lds_lane_ordered && h->opt_level_walk != 1 && (h->opt_level_walk == 2 || pc.n_groups <= simds);
             if (pc.levels_ooo) {
-                pc.levels_threads = 64 * std::min(16, std::max(4, max_tiles_in_group));  // a wave per tile, at least four per group
-                pc.lds_levels = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles);
-            } else {
+                // the levels of a tile's stream live in LDS: room for 24 pairs per particle (a dense island's first
+                // steps: ~20), more after a launch that needed more, never more than the stream itself can hold
+                pc.lev_lds_cap = (int)std::min<size_t>((size_t)pc.scap, std::max<size_t>((size_t)24 * lc.nmax, s.pk_lev_lds_min));
+                pc.lev_lds_cap = (pc.lev_lds_cap + 7) & ~7;
+                pc.levels_threads = 64 * std::min(16, std::max((h->opt_tune & 8) ? 8 : 4, max_tiles_in_group));  // a wave per tile, at least four per group (eight were 10 % slower)
+                pc.lds_levels = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles, max_tiles_in_group, pc.lev_lds_cap);
+                if (pc.lds_levels > h->lds_limit) pc.levels_ooo = 0;  // (a stream too long for LDS: the in-order walk)
+            }
+            if (!pc.levels_ooo) {
                 pc.levels_threads = std::min(256, (max_tiles_in_group * 16 + 63) / 64 * 64);
                 pc.lds_levels = egg_pk_levels_mr_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.levels_threads);
             }
@@ -1310,6 +1319,8 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.n_collision_steps = C;
     A.status = d_stat(s, s.parity);
     A.status_next = d_stat(s, s.parity ^ 1);
+    A.tune = h->opt_tune;
+    A.lev_lds_cap = pc.lev_lds_cap;
 }
 
 int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
@@ -1371,9 +1382,18 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
                        [](const PackedClass &pc) { return pc.threads_lists; }, [](const PackedClass &pc) { return pc.lds_lists; });
             launch_all(EGG_PK_KIND_LEVELS, [](const PackedClass &pc) { return pc.levels_ooo ? egg_pk_levels_ooo_kernel : egg_pk_levels_mr16_kernel; },
                        groups_of, [](const PackedClass &pc) { return pc.levels_threads; }, [](const PackedClass &pc) { return pc.lds_levels; });
-            launch_all(EGG_PK_KIND_SORT, [](const PackedClass &pc) { return pc.lds_sort ? egg_pk_sort_kernel : egg_pk_sort_direct_kernel; },
-                       groups_of, c256,
-                       [&](const PackedClass &pc) { return pc.lds_sort ? pc.lds_sort : egg_align16((size_t)(s.pk_lev_cap + 2) * 4); });
+            {   // (the out-of-order walk sorts inside its own launch)
+                System::PkStamp *ps = nullptr;
+                for (size_t k = 0; k < s.pk.size(); ++k) {
+                    const PackedClass &pc = s.pk[k];
+                    if (pc.levels_ooo) continue;
+                    if (!ps) ps = stamp_begin(EGG_PK_KIND_SORT);
+                    hipLaunchKernelGGL(pc.lds_sort ? egg_pk_sort_kernel : egg_pk_sort_direct_kernel, dim3((unsigned)pc.n_groups), dim3(256),
+                                       pc.lds_sort ? pc.lds_sort : egg_align16((size_t)(s.pk_lev_cap + 2) * 4), st, args[k]);
+                    h->stats.kernel_launches++;
+                }
+                if (ps) (void)hipEventRecord(ps->b, st);
+            }
             // (fewer groups than SIMDs: every executor wave is alone, its time is levels x chain latency)
             const int simds = 4 * std::max(1, h->prop.multiProcessorCount);
             launch_all(EGG_PK_KIND_EXEC, [&](const PackedClass &pc) { return pc.n_groups <= simds ? egg_pk_exec_chain_kernel : egg_pk_exec_kernel; }, groups_of, c64,
@@ -1673,6 +1693,13 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
                 redo = true;
                 continue;
             }
+            if (st.fail_levlds) {
+                // a tile's pair stream outgrew the LDS level array of the out-of-order walk: size it for the longest list seen
+                s.pk_lev_lds_min = std::max<size_t>(2 * s.pk_lev_lds_min, (size_t)(st.max_list * 5 / 4 + 64));
+                s.tiling_dirty = true;
+                redo = true;
+                continue;
+            }
             if (st.fail_levels) {
                 // a group's pair-dependency DAG is deeper than the packed pipeline's level tables: grow and re-run
                 s.pk_lev_cap = std::max(2 * s.pk_lev_cap + 1, st.max_level + 64);
@@ -1745,7 +1772,17 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
             }
             h->stats.max_pass_visits[w] = most;
             h->stats.max_levels[w] = s.pk.empty() ? 0 : st.max_level;
-            if (getenv("EGGSIM_DEBUG") && !s.pk.empty()) fprintf(stderr, "eggsim: type %d step %lld: walk turns (most of any wave in one pass) %llu, levels %d\n", w, (long long)h->stats.steps, st.rounds, st.max_level);
+#ifdef EGG_PROFILE
+            if (getenv("EGGSIM_DEBUG") && !s.pk.empty())
+                fprintf(stderr, "eggsim: type %d step %lld, last pass, egg_pk_levels_ooo cycles: group 0 init %llu rank %llu walk %llu finish %llu sort %llu total %llu | slowest group: walk %llu total %llu | turns %llu levels %d\n",
+                        w, (long long)h->stats.steps, st.visits[55], st.visits[56], st.visits[57], st.visits[58], st.visits[59], st.visits[60], st.visits[61], st.visits[62], st.rounds, st.max_level);
+            if (getenv("EGGSIM_DEBUG") && !s.pk.empty()) {
+                fprintf(stderr, "   group 0 wave 0: %llu turns; cycles waiting for the batch's entries %llu, in the batch set-up %llu, in the turns %llu\n", st.visits[38], st.visits[36], st.visits[39], st.visits[37]);
+                fprintf(stderr, "   groups by total cycles (25k buckets):");
+                for (int k = 0; k < 15; ++k) fprintf(stderr, " %llu", st.visits[40 + k]);
+                fprintf(stderr, "\n");
+            }
+#endif
             h->stats.budget[w] = env[w].budget;
             h->stats.follow_solves += s.n * S;
             s.aabb_on_device = true;  // d_atom_aabb now holds end-of-step cells
@@ -1934,6 +1971,7 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
     }
     (void)hipGetLastError();
     if (const char *e_pk = getenv("EGGSIM_PACKED")) h->opt_packed = atoi(e_pk);  // developer / test override of EGG_OPT_PACKED
+    if (const char *e_tn = getenv("EGGSIM_TUNE")) h->opt_tune = atoi(e_tn);
     if (const char *e_lw = getenv("EGGSIM_LEVEL_WALK")) h->opt_level_walk = std::min(2, std::max(0, atoi(e_lw)));  // developer / test override of EGG_OPT_LEVEL_WALK
     {
         // egg_pk_levels_ooo_kernel ranks the entries of a pair stream with one LDS atomic add per batch and relies on the

@@ -451,7 +451,9 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_stale_kernel(Egg
 // slot of every level in the group's sorted list (level 0 is empty) and the executor's work list: chunks of at most
 // 64 pairs, each inside one level, levels ascending.  An overflowed group is left alone by the later phases (the
 // step is re-run with larger tables).
-__device__ __forceinline__ void pk_levels_finish(const EggPackedArgs &A, int g, const uint32_t *hist, int maxlev, bool over, int lane) {
+// cursor (may be hist itself): receives the first slot of every level as well, for a sort inside the same kernel.
+// Returns whether the group is usable (no table overflowed).
+__device__ __forceinline__ bool pk_levels_finish(const EggPackedArgs &A, int g, const uint32_t *hist, int maxlev, bool over, int lane, uint32_t *cursor = nullptr) {
     const int lev_cap = A.lev_cap;
     if (over && lane == 0) atomicExch(&A.status->fail_levels, 1);
     // the deepest chain of the step (egg_stats.max_levels); most groups see a value that is already larger
@@ -469,6 +471,7 @@ __device__ __forceinline__ void pk_levels_finish(const EggPackedArgs &A, int g, 
         const uint32_t start = carry + incl - v, cb = ccarry + cincl - nch;
         if (L <= nlev) {
             lstart[L] = start;
+            if (cursor) cursor[L] = start;
             for (uint32_t c = 0; c < nch; ++c)
                 if (cb + c < (uint32_t)A.chunk_cap) chunks[cb + c] = (start + 64u * c) | ((min(64u, v - 64u * c) - 1u) << 26);
         }
@@ -481,6 +484,7 @@ __device__ __forceinline__ void pk_levels_finish(const EggPackedArgs &A, int g, 
         A.grp_nchunks[g] = usable ? (int)ccarry : 0;
         A.grp_nlev[g] = usable ? nlev : 0;
     }
+    return usable;
 }
 
 // The in-order walk (throughput regime: more groups than SIMDs, every instruction counts).  One workgroup per group,
@@ -631,6 +635,14 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_levels_mr16_kernel(EggP
     pk_levels_finish(A, g, hist, maxlev, over, lane);
 }
 
+// Diagnostic build (make prof, -DEGG_PROFILE): cycle stamps of the phases of egg_pk_levels_ooo_kernel, group 0 and the
+// slowest group, in the unused tail of EggStatus::visits (printed by the host with EGGSIM_DEBUG=1).  Never in the product.
+#ifdef EGG_PROFILE
+#define EGG_STAMP(name) const unsigned long long name = __builtin_amdgcn_s_memtime()
+#else
+#define EGG_STAMP(name)
+#endif
+
 // The out-of-order walk (latency regime: no more groups than SIMDs, the chip waits for the longest chain).
 //
 // The in-order walk above is serial per tile: a dense 628-particle island with 6,500 pairs takes ~540 turns.  Here the
@@ -650,6 +662,7 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_levels_mr16_kernel(EggP
 // only on finished ones.
 extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggPackedArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
+    EGG_STAMP(TS);
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
@@ -662,7 +675,13 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggP
     unsigned char *q8 = smem + egg_align16((size_t)(lev_cap + 2) * 4);
     uint32_t *word = (uint32_t *)q8;  // [np]
     q8 += egg_align16((size_t)np * 4);
-    uint32_t *cnt = (uint32_t *)q8;   // [np] entries seen so far per particle (the ranking pass)
+    uint32_t *cnt = (uint32_t *)q8;   // [np + 64] entries seen so far per particle (the ranking pass)
+    q8 += egg_align16((size_t)(np + 64) * 4);
+    // [nt][lev_lds_cap] the level of every stream entry.  In LDS because a level stored to global memory inside the walk
+    // would make every wait for the next batch's entries a wait for those stores as well (loads and stores share one
+    // counter, and the number of stores in between is not known at compile time): ~1,500 cycles per batch.
+    uint16_t *llv = (uint16_t *)q8;
+    const int lcap_lds = A.lev_lds_cap;
     __shared__ int tile_base[64], tile_len[64];
     __shared__ int wave_max[16], wave_over[16];
     for (int i = tid; i <= lev_cap + 1; i += nthreads) hist[i] = 0;
@@ -672,9 +691,15 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggP
     }
     if (tid < nt) {  // the group's tiles: first particle (group-local), stream length
         tile_base[tid] = ((const int4 *)A.tile_geo)[2 * (t0 + tid)].x - p0;
-        tile_len[tid] = A.tile_total[t0 + tid];
+        int slen = A.tile_total[t0 + tid];
+        if (slen > lcap_lds) {  // does not fit this launch's LDS: the step is re-run with a larger array
+            atomicExch(&A.status->fail_levlds, 1);
+            slen = 0;
+        }
+        tile_len[tid] = slen;
     }
     __syncthreads();
+    EGG_STAMP(T0);
     // ---- ranking: one wave per tile, stream order.  expect(self) | expect(partner) << 16 per entry, into A.rank.
     // Every lane takes part in all three adds (a branch around an atomic costs a wait for its result): a lane whose
     // add does not apply adds 0 to a spare counter of its own.
@@ -692,19 +717,22 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggP
             for (int u = 0; u < 4; ++u) rec[u] = nxt[u];
 #pragma unroll
             for (int u = 0; u < 4; ++u) nxt[u] = stream[min(e0 + 256 + 64 * u + lane, slen - 1)];  // (the next four batches are on their way)
-            uint32_t xs[4], xo[4];  // (all twelve adds go out before the first result is waited for)
+            uint32_t xs[4], xo[4];  // (all adds go out before the first result is waited for)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool valid = e0 + 64 * u + lane < slen;
                 const int a = (int)(rec[u] & 0x7FFFu), b = (int)((rec[u] >> 16) & 0x7FFFu);
                 const bool up = valid && b > a, down = valid && b < a;
-                const uint32_t x1 = __hip_atomic_fetch_add(&cnt[up ? base + b : spare], up ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                xo[u] = __hip_atomic_fetch_add(&cnt[up ? base + b : spare], up ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __asm__ volatile("" ::: "memory");
+                // (the lanes of a run hit one address and are served in lane order: consecutive numbers)
                 xs[u] = __hip_atomic_fetch_add(&cnt[valid ? base + a : spare], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __asm__ volatile("" ::: "memory");
-                const uint32_t x3 = __hip_atomic_fetch_add(&cnt[down ? base + b : spare], down ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __asm__ volatile("" ::: "memory");
-                xo[u] = up ? x1 : x3;
+                if (__any(down)) {  // stale passes only
+                    const uint32_t x3 = __hip_atomic_fetch_add(&cnt[down ? base + b : spare], down ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __asm__ volatile("" ::: "memory");
+                    xo[u] = up ? xo[u] : x3;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -714,33 +742,46 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggP
         }
     }
     __threadfence_block();
+    EGG_STAMP(T1);
     __syncthreads();
+    EGG_STAMP(T2);
     // ---- the walk.  Fewer tiles than waves: the waves of a tile take its batches round robin; otherwise a wave
     // walks whole tiles alone.
     int maxlev = 0;
+#ifdef EGG_PROFILE
+    unsigned long long acc_read = 0, acc_dec = 0, acc_pro = 0;
+    unsigned int idle_turns = 0;
+#endif
     unsigned int turns = 0;
     bool over = false;
     const int sl = lane & 15, row = lane >> 4;
-    const int wpt = max(1, nwaves / nt), conc = min(nt, nwaves);  // waves per tile, tiles walked side by side
+    const int wpt = min((A.tune & 16) ? 1 : (A.tune & 32) ? 4 : 2, max(1, nwaves / nt)), conc = min(nt, nwaves);  // waves per tile (more than two only slow each other's polls down), tiles walked side by side
     const int sub = wave / conc;
     for (int t = wave % conc; t < nt && sub < wpt; t += conc) {
         const int base = tile_base[t], slen = tile_len[t];
         const uint32_t *stream = A.lists + (size_t)(t0 + t) * A.scap;
         const uint32_t *rank = A.rank + (size_t)(t0 + t) * A.scap;
-        uint16_t *lv = A.lvl + (size_t)(t0 + t) * A.scap;
+        uint16_t *lv = llv + (size_t)t * lcap_lds;
         const int nb = (slen + 63) >> 6;
-        uint32_t n_rec = 0, n_rk = 0;
-        if (sub < nb) {
-            n_rec = stream[min(sub * 64 + lane, slen - 1)];
-            n_rk = rank[min(sub * 64 + lane, slen - 1)];
-        }
-        for (int q = sub; q < nb; q += wpt) {
-            const uint32_t rec = n_rec, rk = n_rk;
+        // The entries (and their ranks) of a batch are requested TWO batches of this wave ahead of their use (a batch is
+        // walked in ~1,500 cycles, less than a trip to memory): two register sets, the loop handles two batches per turn.
+        auto fetch = [&](int q, uint32_t &r, uint32_t &k) {
+            const int e = min(q * 64 + lane, max(slen - 1, 0));
+            r = stream[e];
+            k = rank[e];
+        };
+        uint32_t recA = 0, rkA = 0, recB = 0, rkB = 0;
+        if (sub < nb) fetch(sub, recA, rkA);
+        if (sub + wpt < nb) fetch(sub + wpt, recB, rkB);
+        auto walk_batch = [&](const uint32_t rec, const uint32_t rk, const int q) __attribute__((always_inline)) {
+#ifdef EGG_PROFILE
+            const unsigned long long p0 = __builtin_amdgcn_s_memtime();
+            __asm__ volatile("v_mov_b32 %0, %1\n v_mov_b32 %0, %2" : "=&v"(idle_turns) : "v"(rec), "v"(rk));
+            __asm__ volatile("s_nop 0" ::: "memory");
+            const unsigned long long p1 = __builtin_amdgcn_s_memtime();
+            acc_read += p1 - p0;
+#endif
             const int e = q * 64 + lane;
-            if (q + wpt < nb) {  // the next batch of this wave is requested before this one is walked
-                n_rec = stream[min(e + wpt * 64, slen - 1)];
-                n_rk = rank[min(e + wpt * 64, slen - 1)];
-            }
             const bool valid = e < slen;
             const int a = base + (int)(rec & 0x7FFFu), b = base + (int)((rec >> 16) & 0x7FFFu);
             const uint32_t ea = rk & 0xFFFFu, eb = rk >> 16;
@@ -759,18 +800,34 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggP
             const uint32_t eas = ea - (uint32_t)sl;                   // + f: what word[self] must hold for lane f to go
             const uint32_t ebp = (eb + 1u) << 16, eap = (ea + 1u) << 16;  // the counts this entry leaves behind
             uint16_t *lve = lv + e;
+#ifdef EGG_PROFILE
+            acc_pro += __builtin_amdgcn_s_memtime() - p1;
+#endif
             while (__any(valid && (uint32_t)sl >= f && f < seg_end)) {
                 ++turns;
+#ifdef EGG_PROFILE
+                const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#endif
                 const uint32_t wa = __hip_atomic_load(&word[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t wb = __hip_atomic_load(&word[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef EGG_PROFILE
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+#endif
                 const uint32_t R = (uint32_t)(__ballot((wb >> 16) == eb) >> (row * 16));  // lanes of my row whose partner is ready
                 const uint32_t nr = segmask & ~R & ~((1u << f) - 1u);
                 const uint32_t stop = min((nr ? (uint32_t)__builtin_ctz(nr) : 0xFFFFFFFFu), seg_end);
                 const bool ok = (wa >> 16) == eas + f;
                 const uint32_t pos = (uint32_t)sl - f;
                 const bool fire = valid && ok && pos < stop - f;
+#ifdef EGG_PROFILE
+                if (!__any(fire)) ++idle_turns;
+#endif
                 if (!__any(fire)) {
-                    __builtin_amdgcn_s_sleep(1);
+                    if (A.tune == 1) __builtin_amdgcn_s_sleep(2);
+                    else if (A.tune == 2) __builtin_amdgcn_s_sleep(4);
+                    else if (A.tune == 3) __builtin_amdgcn_s_sleep(8);
+                    else if (A.tune != 4) __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
                 int v = fire ? (int)(wb & 0xFFFFu) - (int)pos : EGG_NEG_LEVEL;
@@ -795,10 +852,26 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggP
                     atomicAdd(&hist[l], 1u);
                 }
                 f = (ok && f < stop) ? stop : f;
+#ifdef EGG_PROFILE
+                acc_dec += __builtin_amdgcn_s_memtime() - q0;
+#endif
+            }
+        };
+        for (int q = sub; q < nb; q += 2 * wpt) {
+            {
+                const uint32_t r = recA, k = rkA;
+                if (q + 2 * wpt < nb) fetch(q + 2 * wpt, recA, rkA);
+                walk_batch(r, k, q);
+            }
+            if (q + wpt < nb) {
+                const uint32_t r = recB, k = rkB;
+                if (q + 3 * wpt < nb) fetch(q + 3 * wpt, recB, rkB);
+                walk_batch(r, k, q + wpt);
             }
         }
     }
     over = maxlev > lev_cap;
+    EGG_STAMP(T3);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) maxlev = max(maxlev, __shfl_xor(maxlev, d, 64));
     over = __any(over);
@@ -808,12 +881,64 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggP
         atomicMax(&A.status->rounds, (unsigned long long)turns);  // (diagnostic: the most turns any wave of the step's walks took)
     }
     __syncthreads();
-    if (tid >= 64) return;
-    for (int w = 0; w < nwaves; ++w) {
-        maxlev = max(maxlev, wave_max[w]);
-        over = over || wave_over[w];
+    EGG_STAMP(T3b);
+    __shared__ int usable_s;
+    if (tid < 64) {
+        for (int w = 0; w < nwaves; ++w) {
+            maxlev = max(maxlev, wave_max[w]);
+            over = over || wave_over[w];
+        }
+        // (hist becomes the sort's cursors in place: every lane reads its level's count before it writes the start)
+        bool lds_ok = true;
+        for (int t = 0; t < nt; ++t) lds_ok = lds_ok && A.tile_total[t0 + t] <= lcap_lds;
+        const bool usable = pk_levels_finish(A, g, hist, maxlev, over || !lds_ok, lane, hist) && lds_ok;
+        if (lane == 0) usable_s = usable ? 1 : 0;
     }
-    pk_levels_finish(A, g, hist, maxlev, over, lane);
+    __syncthreads();
+    EGG_STAMP(T4);
+    if (!usable_s) return;
+    // ---- counting sort of the group's pairs by level (what egg_pk_sort_direct_kernel does for the in-order walk):
+    // indices become group-local, bit 31 marks a pair
+    uint32_t *sorted = A.sorted + (size_t)g * A.sort_cap;
+    for (int t = 0; t < nt; ++t) {
+        const uint32_t base = (uint32_t)tile_base[t];
+        const int slen = tile_len[t];
+        const uint32_t *stream = A.lists + (size_t)(t0 + t) * A.scap;
+        const uint16_t *lv = llv + (size_t)t * lcap_lds;
+        for (int e0 = 0; e0 < slen; e0 += 12 * nthreads) {  // (twelve entries per lane requested before the first is used)
+            uint32_t rec[12], l[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int e = min(e0 + u * nthreads + tid, slen - 1);
+                rec[u] = stream[e];
+                l[u] = (uint32_t)lv[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u)
+                if (e0 + u * nthreads + tid < slen) {
+                    const uint32_t pos = atomicAdd(&hist[l[u]], 1u);
+                    sorted[pos] = 0x80000000u | ((rec[u] & 0x7FFFu) + base) | (rec[u] & 0x8000u) | ((((rec[u] >> 16) & 0x7FFFu) + base) << 16);
+                }
+        }
+    }
+#ifdef EGG_PROFILE
+    __syncthreads();
+    EGG_STAMP(T5);
+    if (tid == 0) {
+        atomicMax(&A.status->visits[62], T5 - TS);
+        atomicMax(&A.status->visits[61], T3 - T2);
+        atomicAdd(&A.status->visits[40 + min(14ull, (T5 - TS) / 25000ull)], 1ull);  // histogram of the groups' total cycles, 25,000 per bucket
+        if (g == 0) {
+            const unsigned long long v[5] = {T0 - TS, T1 - T0, T3 - T2, T4 - T3b, T5 - T4};
+            for (int k = 0; k < 5; ++k) A.status->visits[55 + k] = v[k];
+            A.status->visits[60] = T5 - TS;
+            A.status->visits[36] = acc_read;
+            A.status->visits[37] = acc_dec;
+            A.status->visits[38] = turns;
+            A.status->visits[39] = acc_pro;
+        }
+    }
+#endif
 }
 
 // Does one ds_add_rtn_u32 serve the lanes that hit the same LDS address in ascending lane order?  (What

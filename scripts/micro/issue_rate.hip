@@ -86,6 +86,22 @@ __global__ void probe(int iters, unsigned long long *out, double seed) {
             asm volatile(REP64("v_fma_f64 %0, %0, %2, %3\n v_fma_f64 %1, %1, %2, %3\n") : "+v"(x0), "+v"(x1) : "v"(m), "v"(c));
         } else if (MODE == 19) {  // scalar ALU
             asm volatile(REP64("s_add_u32 s20, s20, 1\n") : : : "s20", "scc");
+        } else if (MODE == 21) {  // LDS atomic add with return, distinct addresses, one at a time (latency)
+            asm volatile(REP16("ds_add_rtn_u32 %0, %1, %2\n s_waitcnt lgkmcnt(0)\n") : "=&v"(u1) : "v"(addr), "v"(u2) : "memory");
+        } else if (MODE == 22) {  // ... sixteen back to back (throughput)
+            asm volatile(REP16("ds_add_rtn_u32 %0, %1, %2\n") "s_waitcnt lgkmcnt(0)\n" : "=&v"(u1) : "v"(addr), "v"(u2) : "memory");
+        } else if (MODE == 23) {  // LDS atomic add without return
+            asm volatile(REP16("ds_add_u32 %0, %1\n") "s_waitcnt lgkmcnt(0)\n" : : "v"(addr), "v"(u2) : "memory");
+        } else if (MODE == 24) {  // with return, all 64 lanes on ONE address
+            asm volatile(REP16("ds_add_rtn_u32 %0, %1, %2\n") "s_waitcnt lgkmcnt(0)\n" : "=&v"(u1) : "v"(addr & 0u), "v"(u2) : "memory");
+        } else if (MODE == 25) {  // with return, 8 lanes active
+            if (lane < 8) asm volatile(REP16("ds_add_rtn_u32 %0, %1, %2\n") "s_waitcnt lgkmcnt(0)\n" : "=&v"(u1) : "v"(addr), "v"(u2) : "memory");
+        } else if (MODE == 26) {  // ds_bpermute_b32
+            asm volatile(REP16("ds_bpermute_b32 %0, %1, %2\n") "s_waitcnt lgkmcnt(0)\n" : "=&v"(u1) : "v"(addr & 0xFCu), "v"(u2) : "memory");
+        } else if (MODE == 27) {  // plain ds_write_b32 for comparison
+            asm volatile(REP16("ds_write_b32 %0, %1\n") "s_waitcnt lgkmcnt(0)\n" : : "v"(addr), "v"(u2) : "memory");
+        } else if (MODE == 28) {  // plain ds_read_b32 for comparison
+            asm volatile(REP16("ds_read_b32 %0, %1\n") "s_waitcnt lgkmcnt(0)\n" : "=&v"(u1) : "v"(addr) : "memory");
         } else if (MODE == 20) {  // LDS read issue rate, independent (no wait until the end of the block)
             asm volatile(REP16("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:16\n") "s_waitcnt lgkmcnt(0)\n"
                          : "=v"(p0), "=v"(p1) : "v"(addr) : "memory");
@@ -143,5 +159,13 @@ int main() {
     ROW(13, "ds_read_b32 pointer chase", 64)
     ROW(14, "2 ds_read_b128, wait, 2 ds_write_b128 of them (per level)", 16)
     ROW(20, "ds_read_b128 independent (per read)", 32)
+    ROW(28, "ds_read_b32 x16 back to back (per read)", 16)
+    ROW(27, "ds_write_b32 x16 back to back (per write)", 16)
+    ROW(21, "ds_add_rtn_u32, distinct addresses, waited (latency)", 16)
+    ROW(22, "ds_add_rtn_u32 x16 back to back (per atomic)", 16)
+    ROW(23, "ds_add_u32 (no return) x16 back to back", 16)
+    ROW(24, "ds_add_rtn_u32 x16, 64 lanes on one address", 16)
+    ROW(25, "ds_add_rtn_u32 x16, 8 lanes active", 16)
+    ROW(26, "ds_bpermute_b32 x16 back to back", 16)
     return 0;
 }

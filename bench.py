@@ -50,7 +50,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_PARTICLE_STEP = 592.0  # SURVEY.md 8d / BASELINE.md: FP64 SoA, state round-trips HBM once per phase
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 PITCH = 160.0                         # px between batch centres (BASELINE config 2: islands never touch)
-COUNTER_FILE = os.path.join(ROOT, "profiles", "r02_counters.json")  # written by scripts/collect_counters.py
+COUNTER_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r03_counters.json", "r02_counters.json")]  # written by scripts/collect_counters.sh; newest first
 
 
 def site_pitch(overlap=1):
@@ -109,6 +109,55 @@ def cpu_baseline(n_batches, overlap, budget_s=12.0):
                       "%.0f x this sample per step" % (sample, overlap, steps, warm, os.cpu_count() or 0, n_batches / sample)}
 
 
+def pk_symbol(kind, variants):
+    """the kernel symbol rocprofv3 shows for a phase of the packed pipeline (egg_stats.pk_variants says which variant runs)"""
+    from egg_fluid_simulation_amd import _ffi
+    if kind == "egg_pk_levels_kernel":
+        names = [n for bit, n in ((_ffi.PK_VARIANT_LEVELS_OOO, "egg_pk_levels_ooo_kernel"), (_ffi.PK_VARIANT_LEVELS_INORDER, "egg_pk_levels_mr16_kernel")) if variants & bit]
+    elif kind == "egg_pk_exec_kernel":
+        names = [n for bit, n in ((_ffi.PK_VARIANT_EXEC_CHAIN, "egg_pk_exec_chain_kernel"), (_ffi.PK_VARIANT_EXEC, "egg_pk_exec_kernel")) if variants & bit]
+    elif kind == "egg_pk_sort_kernel":
+        names = [n for bit, n in ((_ffi.PK_VARIANT_SORT_DIRECT, "egg_pk_sort_direct_kernel"), (_ffi.PK_VARIANT_SORT_LDS, "egg_pk_sort_kernel")) if variants & bit]
+    else:
+        names = [kind]
+    return " / ".join(names) if names else kind
+
+
+def git_commit_of(path):
+    """the commit that last changed a committed measurement file (so that a number read from it can be traced)"""
+    import subprocess
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "log", "-n", "1", "--format=%h", "--", path], capture_output=True, text=True, timeout=10)
+        return out.stdout.strip() or None
+    except Exception:
+        return None
+
+
+def steady_window(make_handler, warmup, steps, n_white):
+    """config 3 never settles (its dependency chains deepen for hundreds of steps): the same scene timed at a later window"""
+    from egg_fluid_simulation_amd import WHITE, _ffi
+    h = make_handler()
+    for _ in range(warmup):
+        h.step(1 / 60, 2, 3)
+    h.set_option(_ffi.OPT_TIMING, 1)
+    h.synchronize()
+    s0 = h.stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.step(1 / 60, 2, 3)
+    h.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = h.stats()
+    kernel_ms = s1["kernel_ms_sum"][WHITE] / max(1, s1["timed_steps"])
+    achieved = ALGO_BYTES_PER_PARTICLE_STEP * n_white / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    out = {"warmup": warmup, "steps": steps, "ms_per_step": 1e3 * dt / steps, "steps_per_sec": steps / dt,
+           "pair_solves_per_sec": (s1["pair_solves"] - s0["pair_solves"]) / dt, "kernel_ms": kernel_ms,
+           "achieved_gbs": achieved, "frac": achieved / HBM_PEAK_GBS, "levels_per_pass": s1.get("max_levels"),
+           "redo_steps": s1["redo_steps"] - s0["redo_steps"]}
+    del h
+    return out
+
+
 def timed_run(h, one_step, steps, warmup, torch, dist, timing_option):
     from egg_fluid_simulation_amd import _ffi
     for _ in range(warmup):
@@ -162,6 +211,8 @@ def main():
     ap.add_argument("--packed", type=int, default=-1, help="packed pipeline: -1 automatic, 0 never, 1 always (A/B testing)")
     ap.add_argument("--group-particles", type=int, default=0, help="packed pipeline: particles per executor wave (0 = default)")
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the per-kernel timing leg (a replay of the timed region on a fresh scene; -1: as many as --steps, 0: none)")
+    ap.add_argument("--no-windows", action="store_true", help="skip the later timing windows of config 3 (config3_protocol, config3_late)")
+    ap.add_argument("--late-warmup", type=int, default=600, help="warm-up steps of the config3_late window")
     args = ap.parse_args()
     if args.profile_steps < 0:
         args.profile_steps = args.steps
@@ -263,7 +314,7 @@ def main():
                 n = sp["pk_kernel_launches"][w][k]
                 if n:
                     groups = n / max(1, sp["packed"][w])  # launches of one kind: one per class of the type
-                    per_kernel.append({"kernel": name, "type": tag, "avg_ms": sp["pk_kernel_ms"][w][k] / groups,
+                    per_kernel.append({"kernel": pk_symbol(name, sp["pk_variants"][w]), "type": tag, "avg_ms": sp["pk_kernel_ms"][w][k] / groups,
                                        "launches_per_step": groups / args.profile_steps,
                                        "ms_per_step": sp["pk_kernel_ms"][w][k] / args.profile_steps})
 
@@ -294,14 +345,19 @@ def main():
             kernel_name = "egg_step_kernel_multi* (one launch, white + yolk tiles)" if fused else "egg_step_kernel* (white launch)"
             dominant = None
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, valu = None, None
-        if os.path.exists(COUNTER_FILE) and world == 1:
+        # rocprofv3 counters cannot be taken from inside the process: they are read from the newest committed counter file
+        # that holds this workload, and the line says which file (and which commit of it) they come from
+        traffic, valu, traffic_source = None, None, None
+        for cf in COUNTER_FILES if world == 1 else []:
             try:
-                c = json.load(open(COUNTER_FILE)).get("%d_%d" % (args.batches, args.overlap))
-                if c:
-                    traffic, valu = c.get("hbm_bytes_per_step"), c.get("valu")
+                c = json.load(open(cf)).get("%d_%d" % (args.batches, args.overlap))
             except Exception:
-                pass
+                c = None
+            if c:
+                traffic, valu = c.get("hbm_bytes_per_step"), c.get("valu")
+                traffic_source = {"file": os.path.relpath(cf, ROOT), "commit": git_commit_of(cf),
+                                  "how": "scripts/collect_counters.sh (rocprofv3 --pmc, one pass per counter set, summed over every launch of a step; 2 x FETCH_SIZE + WRITE_SIZE); NOT measured in this run"}
+                break
         out = {
             "metric": "pair_solves_per_sec", "value": pairs / elapsed, "unit": "pair-solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -322,6 +378,7 @@ def main():
                        "levels_per_pass": s1.get("max_levels")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu,
+                         "traffic_source": traffic_source, "valu_source": traffic_source,
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "dominant_kernel": dominant,
                          "kernel_ms_timed_region": kernel_ms_white,
                          "kernel_ms_yolk_stream": None if fused else kernel_ms_yolk,
@@ -329,6 +386,14 @@ def main():
         }
         if world == 1:
             del h
+            if (args.batches, args.overlap) == (4096, 4) and not args.no_windows:
+                # the headline config is a transient: besides the driver's window (value), the BASELINE.md protocol window
+                # and a late one, each with its own ms_per_step / frac / levels_per_pass
+                if (args.warmup, args.steps) != (10, 100):
+                    out["config3_protocol"] = steady_window(make_handler, 10, 100, n_white)
+                else:
+                    out["config3_protocol"] = "the timed region of this line (10 warm-up + 100 steps)"
+                out["config3_late"] = steady_window(make_handler, args.late_warmup, 50, n_white)
             if not args.no_latency:
                 out["latency_config2"] = latency_config2(torch, local_rank)
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.batches, args.overlap)

@@ -1032,12 +1032,15 @@ int retile(egg_handle *h, int which) {
                 max_tiles_in_group = std::max(max_tiles_in_group, t_end - t);
                 t = t_end;
             }
-            // The level walk.  While the class's groups are no more than the SIMDs, the step waits for the longest
-            // dependency chain of one group: the out-of-order walk (four waves per group level whatever runs are ready;
-            // a dense island's 6,500 pairs: ~150 turns instead of ~540).  On a full chip the in-order walk's fewer
-            // instructions per pair win.
+            // The level walk.  Dense islands (more than 256 particles: thousands of pairs per pass in hundreds of levels)
+            // on a chip that is not full -- groups no more than SIMDs -- wait for the longest dependency chain of one
+            // tile: the out-of-order walk levels whatever runs are ready (a 628-particle island's 6,500 pairs: ~165 turns
+            // instead of ~540) and sorts in the same launch.  Its fixed costs (ranking pass, barriers, ~40 us) lose against
+            // the in-order walk on sparse 157-particle tiles at every scene size (2,048 blobs: 0.41 vs 0.27 ms per step,
+            // 16,384: 1.48 vs 0.54; profiles/r03_walk_sweep.txt), and on a full chip its extra instructions do.
             const int simds = 4 * std::max(1, h->prop.multiProcessorCount);
-            pc.levels_ooo = h->lds_lane_ordered && h->opt_level_walk != 1 && (h->opt_level_walk == 2 || pc.n_groups <= simds);
+            const bool dense_tiles = tiles[(size_t)lc.first_tile].particles > 256;
+            pc.levels_ooo = h->lds_lane_ordered && h->opt_level_walk != 1 && (h->opt_level_walk == 2 || (pc.n_groups <= simds && dense_tiles));
             if (pc.levels_ooo) {
                 // the levels of a tile's stream live in LDS: room for 24 pairs per particle (a dense island's first
                 // steps: ~20), more after a launch that needed more, never more than the stream itself can hold
@@ -1832,7 +1835,7 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase = kWhole) {  //
             for (const PackedClass &pc : s.pk)
                 h->stats.pk_variants[w] |= (pc.levels_ooo ? EGG_PK_VARIANT_LEVELS_OOO : EGG_PK_VARIANT_LEVELS_INORDER) |
                                            (pc.n_groups <= 4 * std::max(1, h->prop.multiProcessorCount) ? EGG_PK_VARIANT_EXEC_CHAIN : EGG_PK_VARIANT_EXEC) |
-                                           (pc.lds_sort ? EGG_PK_VARIANT_SORT_LDS : EGG_PK_VARIANT_SORT_DIRECT);
+                                           (pc.levels_ooo ? 0 : pc.lds_sort ? EGG_PK_VARIANT_SORT_LDS : EGG_PK_VARIANT_SORT_DIRECT);  // (the out-of-order walk sorts in its own launch)
             for (size_t k = 0; h->opt_timing >= 2 && k < s.pk_stamps_used; ++k) {
                 const System::PkStamp &ps = s.pk_stamps[k];
                 float t = 0;

@@ -397,6 +397,10 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
             uint32_t *dst = gstream + own_off[i];
             const double2 wi = all_fast ? make_double2(0.0, 0.0) : ((const double2 *)A.pk_wr)[p0 + i];
             auto emit = [&](int k, int j) {
+                if (all_fast) {  // (no pair of the tile can need the reference path or fail the mass guard: nothing to test)
+                    dst[k] = (uint32_t)i | ((uint32_t)j << 16);
+                    return;
+                }
                 const double2 wj = ((const double2 *)A.pk_wr)[p0 + j];
                 const bool slow = pair_needs_reference(wi, wj, A.overlap_factor, A.collision_compliance, A.eps);
                 // a pair failing the mass guard (L:1601) is marked in `collided` but leaves n_collided alone

@@ -247,7 +247,7 @@ enum {
 /* egg_stats.pk_variants: the kernel a phase of the packed pipeline runs depends on the regime (csrc/eggsim_packed.hip) */
 enum {
     EGG_PK_VARIANT_LEVELS_INORDER = 1, /* egg_pk_levels_mr16_kernel: more groups than SIMDs */
-    EGG_PK_VARIANT_LEVELS_OOO = 2,     /* egg_pk_levels_ooo_kernel: the step waits for the longest chain of one group */
+    EGG_PK_VARIANT_LEVELS_OOO = 2,     /* egg_pk_levels_ooo_kernel (levels + sort in one launch): dense islands on a chip that is not full */
     EGG_PK_VARIANT_EXEC = 4,           /* egg_pk_exec_kernel */
     EGG_PK_VARIANT_EXEC_CHAIN = 8,     /* egg_pk_exec_chain_kernel: branch-free projection, executor waves alone on their SIMDs */
     EGG_PK_VARIANT_SORT_LDS = 16,      /* egg_pk_sort_kernel: sorted list assembled in LDS */
@@ -307,7 +307,7 @@ enum {
     EGG_OPT_FUSE_TYPES,             /* 1 (default): white and yolk tiles share one launch when the chip holds several tiles per CU; 0: one launch per type */
     EGG_OPT_PACKED,                 /* packed pipeline (one launch per phase, pair projections of many islands packed into full waves): -1 automatic (large scenes), 0 never, 1 whenever a launch class is eligible */
     EGG_OPT_GROUP_PARTICLES,        /* packed pipeline: particles whose positions one wave of the pair executor keeps in LDS (0, the default: by scene size, 320..1280) */
-    EGG_OPT_LEVEL_WALK              /* packed pipeline, the pass that gives every pair its dependency level: 0 (default) by regime -- out of order while the groups are no more than the chip's SIMDs, in order on a full chip --, 1 always in order, 2 out of order everywhere */
+    EGG_OPT_LEVEL_WALK              /* packed pipeline, the pass that gives every pair its dependency level: 0 (default) by regime -- out of order for dense islands (> 256 particles) while the groups are no more than the chip's SIMDs, in order otherwise --, 1 always in order, 2 out of order everywhere */
 };
 int egg_set_option(egg_handle *h, int option, double value);
 

@@ -3,7 +3,7 @@
 #   scripts/collect_counters.sh TAG <bench args...>        e.g.  scripts/collect_counters.sh cfg3 --batches 4096 --overlap 4
 # One pass per counter set (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ has 8 slots), no trace flags besides
 # --kernel-trace, the program directly behind `--`.  Raw per-dispatch CSVs land in gpurun_out/cnt_TAG/<set>/,
-# scripts/counters_to_json.py turns them into the entry of profiles/r02_counters.json that bench.py attaches.
+# scripts/counters_to_json.py turns them into the entry of profiles/r03_counters.json that bench.py attaches.
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/cnt_$tag

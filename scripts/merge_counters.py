@@ -1,4 +1,4 @@
-"""Merges gpurun_out/cnt_*/summary.json (scripts/collect_counters.sh) into profiles/r02_counters.json, keyed
+"""Merges gpurun_out/cnt_*/summary.json (scripts/collect_counters.sh) into profiles/r03_counters.json, keyed
 "<batches>_<overlap>" -- the file bench.py reads roofline.traffic / roofline.valu from."""
 import glob
 import json
@@ -6,7 +6,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(ROOT, "profiles", "r02_counters.json")
+dst = os.path.join(ROOT, "profiles", "r03_counters.json")
 out = json.load(open(dst)) if os.path.exists(dst) else {}
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "cnt_*", "summary.json"))):
     try:

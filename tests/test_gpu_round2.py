@@ -271,6 +271,34 @@ def test_packed_pipeline_dense_and_sparse_islands_with_hand_made_chaos(egg, orac
     assert h.stats()["packed"][WHITE] >= 1 and _walk_used(h, walk)
 
 
+@pytest.mark.parametrize("walk", WALKS)
+def test_packed_pipeline_inverse_masses_between_half_eps_and_eps(egg, oracle_mod, walk):
+    """every inverse mass in [eps / 2, eps): the tile-wide 'all pairs take the fast path' test of the list kernel holds
+    (w >= eps / 2), no PAIR fails the mass guard (w_i + w_j >= eps, L:1601) and no particle follows its target
+    (w <= eps, L:1458).  Four coincident batches: more partners per particle than the list kernel stages in LDS, so
+    the entries come from its second enumeration -- which must not test pairs against a lone w_j (n_collided counts
+    every visited pair here)."""
+    from egg_fluid_simulation_amd.default_config import default_configs
+    tweak = dict(min_mass=1.0 / 0.7e-8, max_mass=1.0 / 0.6e-8)
+    w, y = default_configs()
+    w.update(tweak)
+    y.update(tweak)
+    h = _packed(egg, walk, white_config=w, yolk_config=y)
+    o = oracle_mod.Oracle()
+    o.set_config(WHITE, dict(oracle_mod.DEFAULT_WHITE, **tweak))
+    o.set_config(YOLK, dict(oracle_mod.DEFAULT_YOLK, **tweak))
+    centers = [(300.0, 300.0)] * 4 + [(700.0, 300.0), (700.0, 480.0)]
+    for cx, cy in centers:
+        assert h.add(cx, cy, 50, 15) == o.add(cx, cy, 50, 15)
+    for step in range(4):
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+        _same(h, o, step)  # (positions and the pair-solve count)
+    inv = o.field(WHITE, "inv_mass")
+    assert (inv >= 0.5e-8).all() and (inv < 1e-8).all()
+    assert h.stats()["packed"][WHITE] >= 1 and h.stats()["max_tile_particles"][WHITE] == 4 * N_W
+
+
 def test_packed_and_fused_paths_give_the_same_bits(egg):
     from egg_fluid_simulation_amd import _ffi
     n = 400

@@ -2558,7 +2558,7 @@ int egg_export_batch(egg_handle *h, int64_t id, egg_batch_info *info, double *wh
                                             s.y[s.cur ^ 1].p, s.inv_mass.p, s.radius.p,    s.mass_t.p};
         for (int f = 0; f < kExportFields; ++f)
             HIP_TRY(h, hipMemcpyAsync(dst + (size_t)f * at->count, src[f] + at->offset, (size_t)at->count * 8,
-                                      hipMemcpyDeviceToHost, s.stream));
+                                      hipMemcpyDefault, s.stream));  // (dst: host or device memory)
         HIP_TRY(h, hipStreamSynchronize(s.stream));
     }
     return EGG_OK;
@@ -2595,7 +2595,7 @@ int egg_import_batch(egg_handle *h, const egg_batch_info *info, const double *wh
                 HIP_TRY(h, hipMemcpyAsync(arrays[a] + at + cnt, tmp.p, tail * 8, hipMemcpyDeviceToDevice, s.stream));
             }
             HIP_TRY(h, hipMemcpyAsync(arrays[a] + at, src + (size_t)field_of[a] * cnt, (size_t)cnt * 8,
-                                      hipMemcpyHostToDevice, s.stream));
+                                      hipMemcpyDefault, s.stream));  // (src: host or device memory)
         }
         HIP_TRY(h, hipStreamSynchronize(s.stream));
         s.n += cnt;

@@ -16,7 +16,7 @@ batches that provably cannot interact.  Sharding therefore works on whole batche
     this step.  Exact Gauss-Seidel order across a cut cannot be kept in parallel (8e, exactness
     caveat), so that pair must be stepped by ONE rank: ShardedSimulationHandler hands the batch of
     the higher rank over to the lower rank (complete particle state, egg_export_batch /
-    egg_import_batch) before the step, and hands batches that have strayed deep into another slab
+    egg_import_batch; two messages per neighbour and round, device to device over RCCL) before the step, and hands batches that have strayed deep into another slab
     to that slab's rank.  Every handler lays its particles out in ascending global batch id, so the
     result is bit-identical to one handler holding everything.  BoundaryExchange alone (bench.py)
     raises SlabConflict instead of migrating.
@@ -246,6 +246,8 @@ class ShardedSimulationHandler:
         self.radii = {}       # global id -> (white_radius, yolk_radius)
         self.next_gid = 1
         self.migrations = 0
+        self.bytes_handed_over = 0
+        self._committed_visits = [0, 0]  # most pairs one pass of the last committed step visited, per type
         self._elapsed = 0.0
         self.interpolation_alpha = 0.0
         self._budget_stale = True
@@ -323,6 +325,10 @@ class ShardedSimulationHandler:
         # against 0.05 N^2, a rank only sees its own.  While every rank stays below budget / world the global count
         # cannot bind; a rank above it triggers the exact sum -- of THIS step, which is still uncommitted.
         visits, budget = self.local.step_peek_visits()
+        # (the peek sees the FIRST attempt of the step in flight; step_end may re-run it after a failed claim check, and
+        # the step after a hand-over is not peeked at all: what those COMMITTED steps visited is folded into the next
+        # step's test -- a binding budget is then refused one step late instead of never)
+        visits = [max(int(v), int(c)) for v, c in zip(visits, self._committed_visits)]
         suspect = any(v * self.world > max(1.0, math.ceil(b)) for v, b in zip(visits, budget))
         flag = self.torch.tensor([1.0 if conflicts else 0.0, 1.0 if suspect else 0.0, 1.0 if stray else 0.0,
                                   1.0 if wide else 0.0], dtype=self.torch.float64, device=self.device)
@@ -343,13 +349,19 @@ class ShardedSimulationHandler:
                            "than the distance a batch travels in one step plus the halo")
         if flags[0] == 0.0:
             self.local.step_end(True)
+            self._note_committed()
             # a batch that left its slab's halo without meeting anything is handed to the slab it is in before the
             # next step, so that every batch is always known to the ranks on both sides of it
             return self.rebalance() if flags[2] != 0.0 else 0
         self.local.step_end(False)
         moved = self.rebalance()
         self.local.step(delta, n_substeps, n_collision_steps)
+        self._note_committed()
         return moved
+
+    def _note_committed(self):
+        st = self.local.stats()
+        self._committed_visits = [int(v) for v in st["max_pass_visits"]]
 
     def positions(self):
         """{global id: (x, y)} of every batch, gathered on all ranks"""
@@ -411,34 +423,72 @@ class ShardedSimulationHandler:
         self.local.set_option(_ffi.OPT_BUDGET_PARTICLES_YOLK, ny)
         self._budget_stale = False
 
-    def _send_batch(self, gid, to):
-        torch, dist = self.torch, self.dist
-        info, ws, ys = self.local.export_batch(self.local_id[gid])
-        head = torch.tensor([gid, info["target_x"], info["target_y"], info["white_radius"], info["yolk_radius"],
-                             info["n_white"], info["n_yolk"]], dtype=torch.float64, device=self.device)
-        dist.send(head, to)
-        dist.send(torch.from_numpy(ws).reshape(-1).to(self.device), to)
-        dist.send(torch.from_numpy(ys).reshape(-1).to(self.device), to)
-        lid = self.local_id.pop(gid)
-        del self.global_id[lid]
-        self.local.remove(lid)
+    HEAD = 7  # gid, target x, y, white radius, yolk radius, white particles, yolk particles
 
-    def _recv_batch(self, frm):
+    def _send_batches(self, gids, to):
+        """hands the batches `gids` to rank `to`: ONE header message and ONE payload message for all of them.  With the
+        wire tensors on the GPU ("nccl" = RCCL) the particle state goes device to device: egg_export_batch writes it
+        straight into the tensor RCCL sends, nothing passes through host memory."""
         torch, dist = self.torch, self.dist
-        head = torch.zeros(7, dtype=torch.float64, device=self.device)
+        gids = list(gids)
+        if not gids:
+            return
+        on_gpu = str(self.device).startswith("cuda") and hasattr(self.local, "export_batch_to")
+        counts = [self.local.get_n_particles(self.local_id[g]) for g in gids] if on_gpu else None
+        heads, parts = [], []
+        if on_gpu:
+            total = sum(self.STATE_FIELDS * (nw + ny) for nw, ny in counts)
+            payload = torch.empty(total, dtype=torch.float64, device=self.device)
+            off = 0
+            for g, (nw, ny) in zip(gids, counts):
+                w0, y0 = off, off + self.STATE_FIELDS * nw
+                info = self.local.export_batch_to(self.local_id[g], payload.data_ptr() + 8 * w0, payload.data_ptr() + 8 * y0)
+                heads += [g, info["target_x"], info["target_y"], info["white_radius"], info["yolk_radius"], nw, ny]
+                off = y0 + self.STATE_FIELDS * ny
+        else:
+            for g in gids:
+                info, ws, ys = self.local.export_batch(self.local_id[g])
+                heads += [g, info["target_x"], info["target_y"], info["white_radius"], info["yolk_radius"], info["n_white"], info["n_yolk"]]
+                parts += [np.asarray(ws, dtype=np.float64).reshape(-1), np.asarray(ys, dtype=np.float64).reshape(-1)]
+            payload = torch.from_numpy(np.concatenate(parts)).to(self.device)
+        head = torch.tensor(heads, dtype=torch.float64).to(self.device)
+        dist.send(head, to)
+        dist.send(payload, to)
+        self.bytes_handed_over += 8 * (head.numel() + payload.numel())
+        for g in gids:
+            lid = self.local_id.pop(g)
+            del self.global_id[lid]
+            self.local.remove(lid)
+
+    def _recv_batches(self, n, frm):
+        """receives the `n` batches rank `frm` hands over in this round (the plan told every rank how many)"""
+        torch, dist = self.torch, self.dist
+        if n == 0:
+            return []
+        head = torch.zeros(self.HEAD * n, dtype=torch.float64, device=self.device)
         dist.recv(head, frm)
-        hgid, tx, ty, wr, yr, nw, ny = head.cpu().tolist()
-        gid, nw, ny = int(hgid), int(nw), int(ny)
-        ws = torch.zeros(self.STATE_FIELDS * nw, dtype=torch.float64, device=self.device)
-        ys = torch.zeros(self.STATE_FIELDS * ny, dtype=torch.float64, device=self.device)
-        dist.recv(ws, frm)
-        dist.recv(ys, frm)
-        info = dict(key=gid, target_x=tx, target_y=ty, white_radius=wr, yolk_radius=yr, n_white=nw, n_yolk=ny)
-        lid = self.local.import_batch(info, ws.cpu().numpy().reshape(self.STATE_FIELDS, nw),
-                                      ys.cpu().numpy().reshape(self.STATE_FIELDS, ny))
-        self.local_id[gid] = lid
-        self.global_id[lid] = gid
-        return gid
+        rows = head.cpu().numpy().reshape(n, self.HEAD)
+        total = int(sum(self.STATE_FIELDS * (int(r[5]) + int(r[6])) for r in rows))
+        payload = torch.zeros(total, dtype=torch.float64, device=self.device)
+        dist.recv(payload, frm)
+        on_gpu = str(self.device).startswith("cuda") and hasattr(self.local, "import_batch_from")
+        host = None if on_gpu else payload.cpu().numpy()
+        got, off = [], 0
+        for r in rows:
+            gid, nw, ny = int(r[0]), int(r[5]), int(r[6])
+            info = dict(key=gid, target_x=float(r[1]), target_y=float(r[2]), white_radius=float(r[3]), yolk_radius=float(r[4]),
+                        n_white=nw, n_yolk=ny)
+            w0, y0 = off, off + self.STATE_FIELDS * nw
+            if on_gpu:
+                lid = self.local.import_batch_from(info, payload.data_ptr() + 8 * w0, payload.data_ptr() + 8 * y0)
+            else:
+                lid = self.local.import_batch(info, host[w0:y0].reshape(self.STATE_FIELDS, nw),
+                                              host[y0:y0 + self.STATE_FIELDS * ny].reshape(self.STATE_FIELDS, ny))
+            off = y0 + self.STATE_FIELDS * ny
+            self.local_id[gid] = lid
+            self.global_id[lid] = gid
+            got.append(gid)
+        return got
 
     def rebalance(self, max_rounds=None):
         """Before a step: exchange boundary boxes and hand batches over until no local batch is within
@@ -509,17 +559,13 @@ class ShardedSimulationHandler:
             # even ranks send first, odd ranks receive first: neighbour pairs never both block in send
             for phase in (0, 1):
                 if self.rank % 2 == phase:
-                    for g in sorted(to_left):
-                        self._send_batch(g, self.rank - 1)
-                    for g in sorted(to_right):
-                        self._send_batch(g, self.rank + 1)
+                    self._send_batches(sorted(to_left), self.rank - 1)
+                    self._send_batches(sorted(to_right), self.rank + 1)
                 else:
                     if self.rank + 1 < self.world:
-                        for _g in plan[self.rank + 1][0]:
-                            self._recv_batch(self.rank + 1)
+                        self._recv_batches(len(plan[self.rank + 1][0]), self.rank + 1)
                     if self.rank > 0:
-                        for _g in plan[self.rank - 1][1]:
-                            self._recv_batch(self.rank - 1)
+                        self._recv_batches(len(plan[self.rank - 1][1]), self.rank - 1)
             for r, (l, rr) in enumerate(plan):
                 for g in l:
                     self.owner[g] = r - 1

@@ -322,6 +322,20 @@ class SimulationHandler:
         self._check(self._lib.egg_export_batch(self._h, int(batch_id), C.byref(info), ws.ctypes.data, ys.ctypes.data))
         return {k: getattr(info, k) for k, _ in _ffi.EggBatchInfo._fields_}, ws, ys
 
+    def export_batch_to(self, batch_id, white_ptr, yolk_ptr):
+        """export_batch into caller-owned buffers given by ADDRESS (host memory or memory of this handle's device, e.g.
+        torch.Tensor.data_ptr() of a CUDA tensor: a device-to-device hand-over, nothing touches the host); returns info"""
+        info = _ffi.EggBatchInfo()
+        self._check(self._lib.egg_export_batch(self._h, int(batch_id), C.byref(info), C.c_void_p(int(white_ptr)), C.c_void_p(int(yolk_ptr))))
+        return {k: getattr(info, k) for k, _ in _ffi.EggBatchInfo._fields_}
+
+    def import_batch_from(self, info, white_ptr, yolk_ptr):
+        """import_batch from buffers given by address (host or this handle's device memory, field-major [9, n])"""
+        c = _ffi.EggBatchInfo(**{k: info[k] for k, _ in _ffi.EggBatchInfo._fields_})
+        out = C.c_int64()
+        self._check(self._lib.egg_import_batch(self._h, C.byref(c), C.c_void_p(int(white_ptr)), C.c_void_p(int(yolk_ptr)), C.byref(out)))
+        return out.value
+
     def import_batch(self, info, white_state, yolk_state):
         c = _ffi.EggBatchInfo(**{k: info[k] for k, _ in _ffi.EggBatchInfo._fields_})
         ws = np.ascontiguousarray(white_state, dtype=np.float64)

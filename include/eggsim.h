@@ -98,7 +98,9 @@ int egg_add_many(egg_handle *h, int64_t n, const double *xs, const double *ys, d
  * egg_add_many_keyed appends (keys ascending and larger than every key present); egg_export_batch /
  * egg_import_batch move a batch with its complete particle state between handlers, the import
  * inserting it at its key's place.  State layout: 9 fields x n particles, field-major:
- * x, y, vx, vy, last_x, last_y, inv_mass, radius, mass_t. */
+ * x, y, vx, vy, last_x, last_y, inv_mass, radius, mass_t.  The state buffers may be host memory or memory of the
+ * handle's device (the copies use hipMemcpyDefault): a multi-GPU host hands a batch over device to device -- e.g.
+ * straight into and out of the tensors an RCCL send / receive works on -- without a bounce through the host. */
 typedef struct {
     int64_t key;
     double target_x, target_y;

@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch brings its own HIP runtime: it has to be in the process BEFORE libeggsim.so pulls in the system's copy,
+    import torch  # noqa: F401  -- or torch.cuda finds no GPU afterwards (the device-to-device hand-over test uses CUDA tensors)
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -180,3 +180,47 @@ def test_unsupported_configuration_fails_loudly(egg):
     h.add(0, 0, 50, 15)
     with pytest.raises(egg.EggError, match="un-cleared hash generations"):
         h.update(1 / 60, 1 / 60, 9, 1)
+
+
+def test_batch_hand_over_device_to_device_matches_the_host_path(egg, oracle_mod):
+    """egg_export_batch / egg_import_batch with DEVICE buffers (what sharding.py hands to RCCL: the particle state never
+    touches host memory) against the same hand-over through numpy arrays, and both against one oracle that never
+    moved anything"""
+    import torch
+    centers = [(200.0, 200.0), (230.0, 215.0), (600.0, 200.0)]
+    o = oracle_mod.Oracle()
+    for x, y in centers:
+        o.add(x, y, 50, 15)
+    results = []
+    for path in ("device", "host"):
+        a, b = egg.SimulationHandler(), egg.SimulationHandler()
+        ids = a.add_many_keyed([c[0] for c in centers], [c[1] for c in centers], [1, 2, 3], 50, 15)
+        for _ in range(3):
+            a.step(1 / 60, 2, 3)
+        # the two overlapping batches move to handler b, the third stays
+        for lid in ids[:2]:
+            nw, ny = a.get_n_particles(int(lid))
+            if path == "device":
+                buf = torch.empty(9 * (nw + ny), dtype=torch.float64, device="cuda")
+                info = a.export_batch_to(int(lid), buf.data_ptr(), buf.data_ptr() + 8 * 9 * nw)
+                torch.cuda.synchronize()
+                wire = buf.clone()  # (stands for the RCCL transfer)
+                b.import_batch_from(info, wire.data_ptr(), wire.data_ptr() + 8 * 9 * nw)
+            else:
+                info, ws, ys = a.export_batch(int(lid))
+                b.import_batch(info, ws, ys)
+            a.remove(int(lid))
+        for _ in range(3):
+            a.step(1 / 60, 2, 3)
+            b.step(1 / 60, 2, 3)
+        results.append([np.concatenate([b.download(w, f), a.download(w, f)]) for w in (0, 1) for f in ("x", "y", "vx", "vy")])
+    for _ in range(6):
+        o.step(1 / 60, 2, 3)
+    want = [o.field(w, f) for w in (0, 1) for f in ("x", "y", "vx", "vy")]
+    # (the oracle's budget counts all three batches; the split handlers each their own: 0.05 N^2 must not bind either way)
+    assert all(not s["cut"] or s["which"] == 1 for s in o.pass_stats())
+    for got in results:
+        for g, w in zip(got[:4], want[:4]):  # white: no budget cut anywhere
+            assert np.array_equal(g, w)
+    for g_dev, g_host in zip(*results):
+        assert np.array_equal(g_dev, g_host)

@@ -274,3 +274,90 @@ def test_four_ranks_hand_over_from_both_sides_gloo():
     both = [rd for rd in res[1][5] if 1 in rd and 2 in rd]
     assert both, "rank 1 must have received from both neighbours in one hand-over round: %s" % res[1][5]
     assert res[0][6] == res[3][6] >= 3                   # everyone counts the same migrations
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Eight ranks: BASELINE config 5's layout (a square grid of batches at 160 px pitch, cut into 8 x-slabs of equal
+# column count) at reduced size -- 16 columns x 6 rows, two columns per slab -- with every target moving on the
+# gate-B circle (radius 100 px: every batch of a slab's edge column crosses into the neighbour's halo and back, many of
+# them past the cut), plus one batch that runs from the first slab to the last through all seven cuts.
+
+def _scenario8():
+    cols, rows, pitch = 16, 6, 160.0
+    start = {}
+    for r in range(rows):
+        for c in range(cols):
+            start[1 + r * cols + c] = (100.0 + pitch * c, 100.0 + pitch * r)
+    runner = len(start) + 1
+    start[runner] = (60.0, 100.0 + pitch * rows)  # below the grid, in slab 0
+    cuts = [20.0 + 2 * pitch * k for k in range(9)]  # between column pairs: 20, 340, ... 2580
+    return start, runner, cuts, pitch * rows + 100.0
+
+
+def _targets8(start, runner, runner_y, k):
+    import math
+    ang = 2 * math.pi * k / 40
+    out = {g: (x + 100.0 * math.cos(ang) - 100.0, y + 100.0 * math.sin(ang)) for g, (x, y) in start.items() if g != runner}
+    out[runner] = (2540.0, runner_y)
+    return out
+
+
+def _worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from egg_fluid_simulation_amd.sharding import ShardedSimulationHandler, SlabLayout
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        start, runner, cuts, runner_y = _scenario8()
+        sh = ShardedSimulationHandler(SlabLayout(cuts), rank, dist, _FakeHandler, device="cpu")
+        for g in sorted(start):
+            assert sh.add(*start[g]) == g
+        for k in range(120):
+            for g, t in _targets8(start, runner, runner_y, k).items():
+                sh.set_target_position(g, *t)
+            sh.step(1 / 60)
+        q.put((rank, "ok", sh.positions(), dict(sh.owner), sorted(sh.local_id), sh.migrations, sh.bytes_handed_over))
+    except Exception:
+        import traceback
+        q.put((rank, "error: " + traceback.format_exc(), None, None, None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_config5_slab_layout_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        out = q.get(timeout=300)
+        assert out[1] == "ok", out[1]
+        res[out[0]] = out
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    start, runner, cuts, runner_y = _scenario8()
+    ref = _FakeHandler()
+    order = sorted(start)
+    ids = ref.add_many_keyed([start[g][0] for g in order], [start[g][1] for g in order], order)
+    for k in range(120):
+        for g, t in _targets8(start, runner, runner_y, k).items():
+            ref.set_target_position(int(ids[g - 1]), *t)
+        ref.step()
+    want = {g: ref.get_position(int(ids[g - 1])) for g in order}
+    for r in range(8):
+        assert res[r][2] == want, r                      # every rank gathers the same, correct positions
+        assert res[r][3] == res[0][3]                    # and the same owner table
+        assert res[r][5] == res[0][5]                    # and counts the same hand-overs
+    held = sorted(g for r in range(8) for g in res[r][4])
+    assert held == order                                  # no batch lost or duplicated
+    assert res[0][3][runner] == 7                         # the runner crossed all seven cuts
+    assert res[0][5] >= 10                                # ... and batches of the circling edge columns were handed over too
+    assert sum(res[r][6] for r in range(8)) > 0

@@ -14,7 +14,8 @@ this package never imports the CPU oracle under oracle/.
 from . import _ffi
 from .default_config import default_configs
 from .simulation_handler import EggError, EggWarning, SimulationHandler
+from .group import SimulationGroup
 
 WHITE, YOLK = _ffi.WHITE, _ffi.YOLK
 
-__all__ = ["SimulationHandler", "EggError", "EggWarning", "default_configs", "WHITE", "YOLK"]
+__all__ = ["SimulationHandler", "SimulationGroup", "EggError", "EggWarning", "default_configs", "WHITE", "YOLK"]

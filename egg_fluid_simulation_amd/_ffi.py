@@ -110,6 +110,20 @@ _SIGNATURES = {
                                      C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "egg_export_batch": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(EggBatchInfo), C.c_void_p, C.c_void_p]),
     "egg_import_batch": (C.c_int, [C.c_void_p, C.POINTER(EggBatchInfo), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "egg_group_create": (C.c_int, [C.POINTER(EggConfig), C.POINTER(EggConfig), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_void_p)]),
+    "egg_group_destroy": (None, [C.c_void_p]),
+    "egg_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "egg_group_n_devices": (C.c_int32, [C.c_void_p]),
+    "egg_group_handle": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "egg_group_set_halo": (C.c_int, [C.c_void_p, C.c_double]),
+    "egg_group_add": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "egg_group_remove": (C.c_int, [C.c_void_p, C.c_int64]),
+    "egg_group_set_target": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double]),
+    "egg_group_get_position": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "egg_group_update": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "egg_group_step": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32]),
+    "egg_group_owner": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "egg_group_get_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "egg_remove": (C.c_int, [C.c_void_p, C.c_int64]),
     "egg_set_target": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double]),
     "egg_set_targets_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

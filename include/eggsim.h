@@ -313,6 +313,37 @@ enum {
 };
 int egg_set_option(egg_handle *h, int option, double value);
 
+/* ---- several GPUs in one process (csrc/eggsim_group.cpp) -------------------------------------------------------
+ * The multi-device form of the handle for a host that is ONE process (the LuaJIT wrapper): one egg_handle per device
+ * behind one egg_group, x-slabs [cuts[k], cuts[k + 1]) of the plane per device (cuts: n_devices + 1 ascending values;
+ * NULL with one device), global batch ids.  A batch is stepped by the device whose slab held its position when it was
+ * added; batches whose claims for a step come within one spatial-hash cell of each other across devices are handed to
+ * ONE device before that step runs (exact Gauss-Seidel order cannot cross a cut), so the results equal a
+ * single handle's bit for bit.  A collision budget 0.05 N^2 (L:1752-1753) that could bind across devices is refused with
+ * EGG_ERR_UNSUPPORTED.  The same device ordinal may appear more than once (several handles on one GPU: testing).
+ * egg_fluid_simulation_amd/sharding.py is the same protocol between processes over RCCL. */
+typedef struct egg_group egg_group;
+int egg_group_create(const egg_config *white, const egg_config *yolk, int32_t n_devices, const int32_t *devices,
+                     const double *cuts, egg_group **out);
+void egg_group_destroy(egg_group *g);
+const char *egg_group_last_error(const egg_group *g);
+int32_t egg_group_n_devices(const egg_group *g);
+egg_handle *egg_group_handle(egg_group *g, int32_t k); /* the k-th device's handle, for downloads and statistics */
+int egg_group_set_halo(egg_group *g, double halo_px);  /* how far outside its slab an island may idle before it is handed on (64) */
+/* add / remove / set_target_position / get_position / update of SimulationHandler, ids global (L:27-135, L:140-155,
+ * L:254-264, L:281-295, L:168-222) */
+int egg_group_add(egg_group *g, double x, double y, double white_radius, double yolk_radius, int64_t white_n, int64_t yolk_n,
+                  int64_t *out_id);
+int egg_group_remove(egg_group *g, int64_t id);
+int egg_group_set_target(egg_group *g, int64_t id, double x, double y);
+int egg_group_get_position(egg_group *g, int64_t id, double *x, double *y);
+int egg_group_update(egg_group *g, double delta, double step_delta, int32_t n_substeps, int32_t n_collision_steps,
+                     int32_t *out_n_steps);
+int egg_group_step(egg_group *g, double delta, int32_t n_substeps, int32_t n_collision_steps); /* _step directly */
+/* which device index holds batch `id` now, and under which id of that device's handle */
+int egg_group_owner(const egg_group *g, int64_t id, int32_t *device_index, int64_t *local_id);
+int egg_group_get_counters(const egg_group *g, int64_t *migrations, int64_t *discarded_steps);
+
 #ifdef __cplusplus
 }
 #endif

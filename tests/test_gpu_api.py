@@ -224,3 +224,42 @@ def test_batch_hand_over_device_to_device_matches_the_host_path(egg, oracle_mod)
             assert np.array_equal(g, w)
     for g_dev, g_host in zip(*results):
         assert np.array_equal(g_dev, g_host)
+
+
+def test_device_group_behind_the_c_abi_matches_one_oracle(egg, oracle_mod):
+    """egg_group_*: three device handles of ONE process (all on GPU 0 here: the box has one) behind one group, x-slabs cut
+    at 600 and 1200.  A column of blobs is driven across both cuts and through the blobs resting there (islands span
+    devices: the launched step is discarded, the island handed to the lower device, the step re-run), another blob just
+    strays into the next slab.  Every particle against ONE oracle that holds all batches."""
+    centers = [(300.0, 200.0), (300.0, 330.0), (900.0, 260.0), (1500.0, 200.0), (1500.0, 330.0), (450.0, 700.0), (1000.0, 700.0)]
+    centers += [(150.0 + 330.0 * k, 1100.0) for k in range(5)]  # (twelve batches: the yolk budget 0.05 N^2 no longer binds, L:1752-1753)
+    g = egg.SimulationGroup([0, 0, 0], cuts=[0.0, 600.0, 1200.0, 1800.0])
+    o = oracle_mod.Oracle()
+    ids = [g.add(x, y, 50, 15) for x, y in centers]
+    assert ids == [o.add(x, y, 50, 15) for x, y in centers] == list(range(1, 13))
+    assert [g.owner(i)[0] for i in ids] == [0, 0, 1, 2, 2, 0, 1, 0, 0, 1, 1, 2]
+    for k in range(70):
+        tx = min(300.0 + 22.0 * k, 1560.0)
+        for i, y in ((1, 200.0), (2, 330.0)):  # the slab-0 column runs to the right through slab 1 into slab 2
+            g.set_target_position(i, tx, y)
+            o.set_target_position(i, tx, y)
+        g.set_target_position(6, 450.0 + min(6.0 * k, 330.0), 700.0)  # strays into slab 1 without meeting anything
+        o.set_target_position(6, 450.0 + min(6.0 * k, 330.0), 700.0)
+        if k % 2:
+            assert g.update(1 / 60) == 1
+        else:
+            g.step(1 / 60, 2, 3)
+        o.update(1 / 60)
+    c = g.counters()
+    assert c["migrations"] >= 4 and c["discarded_steps"] >= 1, c
+    assert g.owner(1)[0] == 2 and g.owner(6)[0] == 1
+    for which in (0, 1):
+        x, y, b = o.field(which, "x"), o.field(which, "y"), o.field(which, "batch_id")
+        got = g.particles(which)
+        assert sorted(got) == ids
+        for i in ids:
+            assert np.array_equal(got[i][0], x[b == i]) and np.array_equal(got[i][1], y[b == i]), (which, i)
+    for i in ids:
+        assert g.get_position(i) == o.get_position(i)
+    with pytest.raises(egg.EggError):
+        g.get_position(99)

@@ -2710,7 +2710,8 @@ int egg_set_render_config(egg_handle *h, int which, const egg_render_config *cfg
         !std::isfinite(cfg->highlight_strength) || !std::isfinite(cfg->shadow_strength) || !(cfg->outline_thickness <= 256))
         return fail(h, EGG_ERR_INVALID_ARGUMENT, "egg_set_render_config: value out of range");
     h->render.cfg[which] = *cfg;
-    // config.color is a new table now: batches that shared the old one keep it for themselves (L:1307-1311)
+    // config.color is a new table now -- whatever its values: set_*_config deep-copies (L:1307-1311) --, so batches that
+    // shared the old one keep it for themselves.  (Call this where the reference calls set_*_config, not once per frame.)
     for (Batch &b : h->batches) b.own_color[which] = true;
     return EGG_OK;
 }

@@ -167,6 +167,8 @@ function SimulationHandler:add(x, y, white_radius, yolk_radius, white_color, yol
     -- argument handling of the reference's add (simulation_handler.lua:27-120), in its order: defaults, type
     -- assertion, radius / count errors, colour errors and warnings; the particle-count defaults themselves
     -- are computed by the library (EGG_DEFAULT_COUNT = "the caller gave nil"), from the same formula (L:52-58)
+    -- (whether the caller gave a colour decides if the batch gets a table of its own or shares the config's, L:49-50)
+    local given_white, given_yolk = white_color ~= nil, yolk_color ~= nil
     white_color = white_color or self._white_config.color
     yolk_color = yolk_color or self._yolk_config.color
     log.assert(x, "number", y, "number")
@@ -211,9 +213,9 @@ function SimulationHandler:add(x, y, white_radius, yolk_radius, white_color, yol
         yolk_n_particles and math.ceil(yolk_n_particles) or EGG_DEFAULT_COUNT, id))
     local batch_id = tonumber(id[0])
     -- a batch created without a colour shares the config's colour table (simulation_handler.lua:49-50)
-    self._batch_colors[batch_id] = { white_color or self._white_config.color, yolk_color or self._yolk_config.color }
-    if white_color ~= nil then lib.egg_set_add_color(self._h, batch_id, 0, white_color[1], white_color[2], white_color[3], white_color[4]) end
-    if yolk_color ~= nil then lib.egg_set_add_color(self._h, batch_id, 1, yolk_color[1], yolk_color[2], yolk_color[3], yolk_color[4]) end
+    self._batch_colors[batch_id] = { white_color, yolk_color }
+    if given_white then lib.egg_set_add_color(self._h, batch_id, 0, white_color[1], white_color[2], white_color[3], white_color[4]) end
+    if given_yolk then lib.egg_set_add_color(self._h, batch_id, 1, yolk_color[1], yolk_color[2], yolk_color[3], yolk_color[4]) end
     return batch_id
 end
 

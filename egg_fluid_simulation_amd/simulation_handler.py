@@ -368,7 +368,8 @@ class SimulationHandler:
             for which in range(2):
                 p.canvas_w[which], p.canvas_h[which] = int(canvas_sizes[which][0]), int(canvas_sizes[which][1])
         p.clear[:] = [float(c) for c in clear]
-        self._send_render_config()
+        # (the render config is NOT re-sent here: egg_set_render_config means "set_*_config was called" -- a new colour
+        # table, L:1307-1311 -- and would end the sharing of the old one between the config and its colourless batches)
         image = np.empty((p.screen_h, p.screen_w, 4), dtype=np.float32)
         self._check(self._lib.egg_render(self._h, C.byref(p), image.ctypes.data_as(C.c_void_p)))
         return image
@@ -497,8 +498,9 @@ class SimulationHandler:
             table[:] = rgba
         else:
             self._batch_colors[int(batch_id)][which] = rgba
-        self._lib.egg_set_color(self._h, int(batch_id), int(which), *[float(c) for c in rgba])  # its particles (L:1110-1129)
-        self._send_render_config()
+        # its particles (L:1110-1129) and, when the batch shares the config's table, the config's colour: the library
+        # applies the same aliasing as the tables above
+        self._lib.egg_set_color(self._h, int(batch_id), int(which), *[float(c) for c in rgba])
 
     def set_white_color(self, batch_id, r, g, b, a=None, *outline):  # L:365-394
         self._set_color("set_white_color", 0, batch_id, r, g, b, a)

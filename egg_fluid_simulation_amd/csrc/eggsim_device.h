@@ -1,4 +1,4 @@
-// eggsim_device.h -- structs shared by the host side (eggsim_host.cpp) and the
+// eggsim_device.h -- structs shared by the host side (eggsim_host_*.hip) and the
 // gfx950 kernels (eggsim_step.hip).  Not part of the public ABI.
 #pragma once
 #include <stdint.h>

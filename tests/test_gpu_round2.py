@@ -322,7 +322,7 @@ def test_packed_and_fused_paths_give_the_same_bits(egg):
 
 def test_one_flying_blob_among_resting_ones(egg, oracle_mod):
     """A blob sent across a field of resting blobs: its swept claim is many times wider than the others' (the host's
-    bucket grid treats it apart, eggsim_host.hip retile) and it merges with whatever it crosses on the way."""
+    bucket grid treats it apart, eggsim_host_tiling.hip retile) and it merges with whatever it crosses on the way."""
     xs, ys = _grid_xy(6)
     h = egg.SimulationHandler()
     o = oracle_mod.Oracle()

@@ -118,6 +118,8 @@ def pk_symbol(kind, variants):
         names = [n for bit, n in ((_ffi.PK_VARIANT_EXEC_CHAIN, "egg_pk_exec_chain_kernel"), (_ffi.PK_VARIANT_EXEC, "egg_pk_exec_kernel")) if variants & bit]
     elif kind == "egg_pk_sort_kernel":
         names = [n for bit, n in ((_ffi.PK_VARIANT_SORT_DIRECT, "egg_pk_sort_direct_kernel"), (_ffi.PK_VARIANT_SORT_LDS, "egg_pk_sort_kernel")) if variants & bit]
+    elif kind == "egg_pk_pass_kernel":
+        names = ["egg_pk_levexec_kernel"]
     else:
         names = [kind]
     return " / ".join(names) if names else kind

@@ -42,6 +42,7 @@ OPT_PACKED = 10
 OPT_GROUP_PARTICLES = 11
 OPT_LEVEL_WALK = 12
 PK_VARIANT_LEVELS_INORDER, PK_VARIANT_LEVELS_OOO, PK_VARIANT_EXEC, PK_VARIANT_EXEC_CHAIN, PK_VARIANT_SORT_LDS, PK_VARIANT_SORT_DIRECT = 1, 2, 4, 8, 16, 32
+PK_VARIANT_PASS_FUSED = 64
 
 CONFIG_FIELDS = ["damping", "follow_strength", "cohesion_strength",
                  "cohesion_interaction_distance_factor", "collision_strength",
@@ -73,7 +74,7 @@ class EggStats(C.Structure):
                 ("last_step_kernel_ms", C.c_double), ("single_tile", C.c_int64 * 2),
                 ("kernel_ms", C.c_double * 2), ("kernel_ms_sum", C.c_double * 2), ("timed_steps", C.c_int64),
                 ("max_pass_visits", C.c_int64 * 2), ("budget", C.c_double * 2), ("fused_launch", C.c_int64),
-                ("packed", C.c_int64 * 2), ("pk_kernel_ms", (C.c_double * 9) * 2), ("pk_kernel_launches", (C.c_int64 * 9) * 2),
+                ("packed", C.c_int64 * 2), ("pk_kernel_ms", (C.c_double * 10) * 2), ("pk_kernel_launches", (C.c_int64 * 10) * 2),
                 ("host_ms", C.c_double * 3), ("max_levels", C.c_int64 * 2), ("pk_variants", C.c_int64 * 2)]
 
 
@@ -91,7 +92,8 @@ class EggRenderParams(C.Structure):  # egg_render_params
 
 
 PK_KINDS = ["egg_pk_begin_kernel", "egg_pk_mid_kernel", "egg_pk_lists_fresh_kernel", "egg_pk_lists_stale_kernel",
-            "egg_pk_levels_kernel", "egg_pk_sort_kernel", "egg_pk_exec_kernel", "egg_pk_end_kernel", "egg_pk_reduce_kernel"]
+            "egg_pk_levels_kernel", "egg_pk_sort_kernel", "egg_pk_exec_kernel", "egg_pk_end_kernel", "egg_pk_reduce_kernel",
+            "egg_pk_pass_kernel"]
 
 
 # every symbol include/eggsim.h declares, with its signature

@@ -182,7 +182,6 @@ struct EggPackedArgs {
 // dynamic LDS of egg_pk_lists for the geometry above (must match eggsim_packed.hip)
 static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int use_grid, int stage_cap) {
     size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, b = 0;
-    b += egg_align16(n * 16);                     // pos
     b += egg_align16(2 * n * 4);                  // ckey[2]
     b += egg_align16(2 * c * 4);                  // cell[2]
     b += egg_align16(use_grid ? 0 : 2 * c * 4);   // hkeys[2]

@@ -50,6 +50,7 @@ extern "C" __global__ void egg_pk_levels_ooo_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_probe_lds_order_kernel(int trials, unsigned long long *bad);
 extern "C" __global__ void egg_pk_exec_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_exec_chain_kernel(EggPackedArgs A);
+extern "C" __global__ void egg_pk_levexec_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_sort_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_sort_direct_kernel(EggPackedArgs A);
 extern "C" __global__ void egg_pk_end_kernel(EggPackedArgs A);
@@ -174,6 +175,8 @@ struct PackedClass {
     int group_base = 0;     // first slot in the per-group arrays
     size_t meta_tile_geo = 0, meta_grp_geo = 0;  // offsets (ints) into System::pk_meta
     int max_group_particles = 0;
+    int fused_pass = 0;     // 1: levels, sort and executor of a group are ONE launch (egg_pk_levexec_kernel)
+    size_t lds_pass = 0;    // its dynamic LDS: the larger of the two phases
     int lev_lds_cap = 0;    // out-of-order walk: stream entries per tile whose levels the LDS of the launch holds
     int levels_ooo = 0;     // the level walk of the class: 0 in order (egg_pk_levels_mr16_kernel), 1 out of order (egg_pk_levels_ooo_kernel)
     int levels_threads = 64; // workgroup of the level walk (up to four waves per group)
@@ -258,6 +261,7 @@ struct System {  // one particle type
     size_t pk_entries = 0;                   // stream words over all packed tiles
     size_t pk_sort_words = 0;                // sorted-list words over all packed groups
     int pk_lev_cap = 255;                    // levels the tables hold; grows when a group's DAG is deeper
+    unsigned long long pk_seen_list = 0;     // longest pair stream any packed tile had in one pass of the last committed step
     size_t pk_lev_lds_min = 0;               // out-of-order walk: smallest LDS level array (entries per tile) after a fail_levlds
     bool pk_plan_dirty = true;
     // EGG_OPT_TIMING = 2: one event pair per launch group of the packed pipeline, read back when the step is committed

@@ -86,6 +86,7 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
         if (e == hipSuccess)
             for (const void *f : {(const void *)egg_pk_lists_fresh_kernel, (const void *)egg_pk_lists_stale_kernel,
                                   (const void *)egg_pk_exec_kernel, (const void *)egg_pk_exec_chain_kernel,
+                                  (const void *)egg_pk_levexec_kernel,
                                   (const void *)egg_pk_sort_kernel, (const void *)egg_pk_levels_mr16_kernel,
                                   (const void *)egg_pk_levels_ooo_kernel, (const void *)egg_render_splat_kernel})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);

@@ -231,15 +231,20 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
         (void)hipEventRecord(ps->a, st);
         return ps;
     };
-    auto launch_all = [&](int kind, auto kernel_of, auto grid_of, auto block_of, auto lds_of) {
-        System::PkStamp *ps = stamp_begin(kind);
+    // one launch per class that `take` selects (0: every class, 1: the classes with one launch per phase, 2: the classes
+    // whose levels, sort and executor are ONE launch, egg_pk_levexec_kernel)
+    auto launch_some = [&](int take, int kind, auto kernel_of, auto grid_of, auto block_of, auto lds_of) {
+        System::PkStamp *ps = nullptr;
         for (size_t k = 0; k < s.pk.size(); ++k) {
             const PackedClass &pc = s.pk[k];
+            if ((take == 1 && pc.fused_pass) || (take == 2 && !pc.fused_pass)) continue;
+            if (!ps) ps = stamp_begin(kind);
             hipLaunchKernelGGL(kernel_of(pc), dim3((unsigned)grid_of(pc)), dim3((unsigned)block_of(pc)), lds_of(pc), st, args[k]);
             h->stats.kernel_launches++;
         }
         if (ps) (void)hipEventRecord(ps->b, st);
     };
+    auto launch_all = [&](int kind, auto kernel_of, auto grid_of, auto block_of, auto lds_of) { launch_some(0, kind, kernel_of, grid_of, block_of, lds_of); };
     auto flat_grid = [](const PackedClass &pc) { return (pc.p_end - pc.p_begin + 255) / 256; };
     auto c256 = [](const PackedClass &) { return 256; };
     auto c64 = [](const PackedClass &) { return 64; };
@@ -261,16 +266,16 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
                 A.substep = sub;
                 A.stale = stale ? 1 : 0;
             }
-            launch_all(stale ? EGG_PK_KIND_LISTS_STALE : EGG_PK_KIND_LISTS_FRESH,
-                       [&](const PackedClass &) { return stale ? egg_pk_lists_stale_kernel : egg_pk_lists_fresh_kernel; }, tiles_of,
-                       [](const PackedClass &pc) { return pc.threads_lists; }, [](const PackedClass &pc) { return pc.lds_lists; });
-            launch_all(EGG_PK_KIND_LEVELS, [](const PackedClass &pc) { return pc.levels_ooo ? egg_pk_levels_ooo_kernel : egg_pk_levels_mr16_kernel; },
-                       groups_of, [](const PackedClass &pc) { return pc.levels_threads; }, [](const PackedClass &pc) { return pc.lds_levels; });
+            launch_some(0, stale ? EGG_PK_KIND_LISTS_STALE : EGG_PK_KIND_LISTS_FRESH,
+                        [&](const PackedClass &) { return stale ? egg_pk_lists_stale_kernel : egg_pk_lists_fresh_kernel; }, tiles_of,
+                        [](const PackedClass &pc) { return pc.threads_lists; }, [](const PackedClass &pc) { return pc.lds_lists; });
+            launch_some(1, EGG_PK_KIND_LEVELS, [](const PackedClass &pc) { return pc.levels_ooo ? egg_pk_levels_ooo_kernel : egg_pk_levels_mr16_kernel; },
+                        groups_of, [](const PackedClass &pc) { return pc.levels_threads; }, [](const PackedClass &pc) { return pc.lds_levels; });
             {   // (the out-of-order walk sorts inside its own launch)
                 System::PkStamp *ps = nullptr;
                 for (size_t k = 0; k < s.pk.size(); ++k) {
                     const PackedClass &pc = s.pk[k];
-                    if (pc.levels_ooo) continue;
+                    if (pc.levels_ooo || pc.fused_pass) continue;
                     if (!ps) ps = stamp_begin(EGG_PK_KIND_SORT);
                     hipLaunchKernelGGL(pc.lds_sort ? egg_pk_sort_kernel : egg_pk_sort_direct_kernel, dim3((unsigned)pc.n_groups), dim3(256),
                                        pc.lds_sort ? pc.lds_sort : egg_align16((size_t)(s.pk_lev_cap + 2) * 4), st, args[k]);
@@ -280,8 +285,11 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
             }
             // (fewer groups than SIMDs: every executor wave is alone, its time is levels x chain latency)
             const int simds = 4 * std::max(1, h->prop.multiProcessorCount);
-            launch_all(EGG_PK_KIND_EXEC, [&](const PackedClass &pc) { return pc.n_groups <= simds ? egg_pk_exec_chain_kernel : egg_pk_exec_kernel; }, groups_of, c64,
-                       [&](const PackedClass &pc) { return pc.lds_exec + (pc.n_groups <= simds ? 64 * 16 : 0); });
+            launch_some(1, EGG_PK_KIND_EXEC, [&](const PackedClass &pc) { return pc.n_groups <= simds ? egg_pk_exec_chain_kernel : egg_pk_exec_kernel; }, groups_of, c64,
+                        [&](const PackedClass &pc) { return pc.lds_exec + (pc.n_groups <= simds ? 64 * 16 : 0); });
+            // dense islands on a chip that is not full: levels, sort and executor of a group in one launch
+            launch_some(2, EGG_PK_KIND_PASS, [](const PackedClass &) { return egg_pk_levexec_kernel; }, groups_of, c256,
+                        [](const PackedClass &pc) { return pc.lds_pass; });
         }
     }
     launch_all(EGG_PK_KIND_END, [](const PackedClass &) { return egg_pk_end_kernel; }, tiles_of,
@@ -578,7 +586,8 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
             }
             if (st.fail_levlds) {
                 // a tile's pair stream outgrew the LDS level array of the out-of-order walk: size it for the longest list seen
-                s.pk_lev_lds_min = std::max<size_t>(2 * s.pk_lev_lds_min, (size_t)(st.max_list * 5 / 4 + 64));
+                s.pk_lev_lds_min = std::max<size_t>(s.pk_lev_lds_min, (size_t)(st.max_list * 5 / 4 + 256));
+                s.pk_seen_list = std::max(s.pk_seen_list, st.max_list);
                 s.tiling_dirty = true;
                 redo = true;
                 continue;
@@ -655,6 +664,7 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
             }
             h->stats.max_pass_visits[w] = most;
             h->stats.max_levels[w] = s.pk.empty() ? 0 : st.max_level;
+            if (!s.pk.empty()) s.pk_seen_list = st.max_list;
 #ifdef EGG_PROFILE
             if (getenv("EGGSIM_DEBUG") && !s.pk.empty())
                 fprintf(stderr, "eggsim: type %d step %lld, last pass, egg_pk_levels_ooo cycles: group 0 init %llu rank %llu walk %llu finish %llu sort %llu total %llu | slowest group: walk %llu total %llu | turns %llu levels %d\n",
@@ -715,7 +725,8 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
             for (const PackedClass &pc : s.pk)
                 h->stats.pk_variants[w] |= (pc.levels_ooo ? EGG_PK_VARIANT_LEVELS_OOO : EGG_PK_VARIANT_LEVELS_INORDER) |
                                            (pc.n_groups <= 4 * std::max(1, h->prop.multiProcessorCount) ? EGG_PK_VARIANT_EXEC_CHAIN : EGG_PK_VARIANT_EXEC) |
-                                           (pc.levels_ooo ? 0 : pc.lds_sort ? EGG_PK_VARIANT_SORT_LDS : EGG_PK_VARIANT_SORT_DIRECT);  // (the out-of-order walk sorts in its own launch)
+                                           (pc.levels_ooo ? 0 : pc.lds_sort ? EGG_PK_VARIANT_SORT_LDS : EGG_PK_VARIANT_SORT_DIRECT) |  // (the out-of-order walk sorts in its own launch)
+                                           (pc.fused_pass ? EGG_PK_VARIANT_PASS_FUSED : 0);
             for (size_t k = 0; h->opt_timing >= 2 && k < s.pk_stamps_used; ++k) {
                 const System::PkStamp &ps = s.pk_stamps[k];
                 float t = 0;

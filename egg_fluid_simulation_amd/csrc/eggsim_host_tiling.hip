@@ -431,7 +431,7 @@ int retile(egg_handle *h, int which) {
                 if (lds > h->lds_limit) return (size_t)0;  // (what a workgroup may have is a little less than the CU's 160 KiB)
                 return std::min<size_t>(kLdsMax / std::max<size_t>(lds, 1), (size_t)2048 / (size_t)pc.threads_lists);
             };
-            for (pc.stage_cap = 16; pc.stage_cap > 0; pc.stage_cap -= 4)
+            for (pc.stage_cap = 16; pc.stage_cap > 0; pc.stage_cap -= 2)
                 if (tiles_per_cu(pc.stage_cap) == tiles_per_cu(0)) break;
             pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap);
             if (pc.lds_lists > h->lds_limit) continue;
@@ -511,12 +511,17 @@ int retile(egg_handle *h, int which) {
             if (pc.levels_ooo) {
                 // the levels of a tile's stream live in LDS: room for 24 pairs per particle (a dense island's first
                 // steps: ~20), more after a launch that needed more, never more than the stream itself can hold
-                pc.lev_lds_cap = (int)std::min<size_t>((size_t)pc.scap, std::max<size_t>((size_t)24 * lc.nmax, s.pk_lev_lds_min));
+                // (once steps have run: a quarter more than the longest list any tile had in the last step -- a fused pass keeps
+                // its LDS small enough for four islands per CU that way; a launch that needs more says so and is re-run)
+                const size_t guess = s.pk_seen_list ? (size_t)(s.pk_seen_list * 5 / 4 + 256) : (size_t)24 * lc.nmax;
+                pc.lev_lds_cap = (int)std::min<size_t>((size_t)pc.scap, std::max<size_t>(guess, s.pk_lev_lds_min));
                 pc.lev_lds_cap = (pc.lev_lds_cap + 7) & ~7;
                 pc.levels_threads = 64 * std::min(16, std::max((h->opt_tune & 8) ? 8 : 4, max_tiles_in_group));  // a wave per tile, at least four per group (eight were 10 % slower)
                 pc.lds_levels = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles, max_tiles_in_group, pc.lev_lds_cap);
                 if (pc.lds_levels > h->lds_limit) pc.levels_ooo = 0;  // (a stream too long for LDS: the in-order walk)
             }
+            // (levels + sort + executor in one launch: whenever the out-of-order walk runs with four waves in the latency regime)
+            pc.fused_pass = pc.levels_ooo && pc.levels_threads == 256 && pc.n_groups <= simds && !(h->opt_tune & 64);
             if (!pc.levels_ooo) {
                 pc.levels_threads = std::min(256, (max_tiles_in_group * 16 + 63) / 64 * 64);
                 pc.lds_levels = egg_pk_levels_mr_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.levels_threads);
@@ -530,7 +535,15 @@ int retile(egg_handle *h, int which) {
                 s.pk_meta_host.resize(meta_mark);
                 continue;
             }
+            if (pc.fused_pass) {
+                pc.lds_pass = std::max(pc.lds_levels, pc.lds_exec + 64 * 16);
+                if (pc.lds_pass > h->lds_limit) pc.fused_pass = 0;
+            }
             pc.sort_cap = (int)sort_words;
+            if (getenv("EGGSIM_DEBUG"))
+                fprintf(stderr, "eggsim: type %d packed class: %d tiles of <= %d particles in %d groups, grid cells %d (%s), lists: %d threads, %d staged partners, %zu B LDS; levels: %s, %d threads, %zu B LDS (level array %d entries); pass fused %d, %zu B LDS\n",
+                        which, lc.n_tiles, lc.nmax, pc.n_groups, lc.ccap, lc.use_grid ? "dense grid" : "hash", pc.threads_lists, pc.stage_cap, pc.lds_lists,
+                        pc.levels_ooo ? "out of order" : "in order", pc.levels_threads, pc.lds_levels, pc.lev_lds_cap, pc.fused_pass, pc.lds_pass);
             pc.chunk_base = s.pk_chunk_words;
             s.pk_chunk_words += (size_t)pc.n_groups * (size_t)pc.chunk_cap;
             lc.packed = (int)s.pk.size();

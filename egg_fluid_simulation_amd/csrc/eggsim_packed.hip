@@ -248,10 +248,9 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_mid_kernel(EggPackedArg
 // ------------------------------------------------------------------------------------------------
 // One collision pass, phase 1: spatial hash + visit lists of a tile.
 template <bool STALE>
-__device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
+__device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const int tile) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int tile = blockIdx.x;
     if (tile >= A.n_tiles) return;
     Tile t;
     uint32_t *own_off, *tmp;
@@ -259,7 +258,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     {
         const size_t n = (size_t)A.nmax, a = (size_t)A.amax, cc = (size_t)A.ccap;
         unsigned char *p = smem;
-        t.pos = (double2 *)carve(p, n * 16);
+        t.pos = nullptr;  // (positions are only needed for the cells: each thread keeps its first particle's in registers)
         t.wr = nullptr;  // (inverse mass, radius) stay in global memory: only the rare slow-pair test reads them per pair
         t.ckey_b = (uint32_t *)carve(p, 2 * n * 4);
         t.cell_b = (uint32_t *)carve(p, 2 * cc * 4);
@@ -306,8 +305,8 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     const int cur = 0, prev = 1;  // LDS generation buffers of this launch
     uint32_t *g_ckey_cur = A.pk_ckey + (size_t)(A.substep & 1) * A.pk_stride + p0;
     const uint32_t *g_ckey_prev = A.pk_ckey + (size_t)((A.substep + 1) & 1) * A.pk_stride + p0;
+    const double2 first_pos = ((const double2 *)A.pk_pos)[p0 + min(tid, max(n - 1, 0))];  // (requested now, used after the next barrier)
     for (int i = tid; i < n; i += nthreads) {
-        t.pos[i] = ((const double2 *)A.pk_pos)[p0 + i];
         t.aslot[i] = A.pk_aslot[p0 + i];
         if (STALE) t.ckey(prev)[i] = g_ckey_prev[i];
     }
@@ -334,7 +333,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
     // ----------------------------------- spatial hash of this pass, L:1486-1511 (claim check as in egg_step_body)
     bool bad = false;
     for (int i = tid; i < n; i += nthreads) {
-        const double2 ps = t.pos[i];
+        const double2 ps = i == tid ? first_pos : ((const double2 *)A.pk_pos)[p0 + i];
         const double fcx = floor(ps.x / A.cell_size);
         const double fcy = floor(ps.y / A.cell_size);
         const int32_t *cl = &t.aclaim[4 * t.aslot[i]];
@@ -440,8 +439,8 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A) {
             (fits && !any_bad) ? total - (int)gsum : 0;
     }
 }
-extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_fresh_kernel(EggPackedArgs A) { egg_pk_lists_body<false>(A); }
-extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_stale_kernel(EggPackedArgs A) { egg_pk_lists_body<true>(A); }
+extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_fresh_kernel(EggPackedArgs A) { egg_pk_lists_body<false>(A, blockIdx.x); }
+extern "C" __global__ void __launch_bounds__(1024) egg_pk_lists_stale_kernel(EggPackedArgs A) { egg_pk_lists_body<true>(A, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // Phase 2: levels.
@@ -664,12 +663,12 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_levels_mr16_kernel(EggP
 // longest prefix whose partners are at theirs -- the same prefix-maximum formula as above -- and publishes the new
 // words; other waves see them on their next poll.  Deadlock-free: the oldest unfinished entry of the stream depends
 // only on finished ones.
-extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggPackedArgs A) {
+// (nthreads: the threads of the workgroup that take part -- all of them, or the first four waves of a fused pass)
+__device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const int g, const int nthreads) {
     extern __shared__ __align__(16) unsigned char smem[];
     EGG_STAMP(TS);
-    const int g = blockIdx.x;
     if (g >= A.n_groups) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int4 gg = ((const int4 *)A.grp_geo)[g];
     const int t0 = __builtin_amdgcn_readfirstlane(gg.x), t1 = __builtin_amdgcn_readfirstlane(gg.y);
     const int p0 = __builtin_amdgcn_readfirstlane(gg.z), np = __builtin_amdgcn_readfirstlane(gg.w);
@@ -945,6 +944,8 @@ extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggP
 #endif
 }
 
+extern "C" __global__ void __launch_bounds__(1024) egg_pk_levels_ooo_kernel(EggPackedArgs A) { pk_levels_ooo_body(A, blockIdx.x, blockDim.x); }
+
 // Does one ds_add_rtn_u32 serve the lanes that hit the same LDS address in ascending lane order?  (What
 // egg_pk_levels_ooo_kernel's ranking pass relies on.)  Pseudo-random keys from key spaces of 1 .. 1000 values; every
 // mismatch against the exact count of earlier lanes with the same key is counted.
@@ -1037,9 +1038,8 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_sort_direct_kernel(EggP
 // alone on their SIMDs (time = levels x chain latency); on a full chip the branches skip work that the lanes of other
 // waves could use, and win by 2 %.
 template <bool PREDICATED>
-__device__ __forceinline__ void egg_pk_exec_body(const EggPackedArgs &A) {
+__device__ __forceinline__ void egg_pk_exec_body(const EggPackedArgs &A, const int g) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int g = blockIdx.x;
     if (g >= A.n_groups) return;
     const int lane = threadIdx.x;
     const int nch = A.grp_nchunks[g];
@@ -1133,8 +1133,27 @@ __device__ __forceinline__ void egg_pk_exec_body(const EggPackedArgs &A) {
     }
     for (int i = lane; i < np; i += 64) gpos[i] = lpos[i];
 }
-extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArgs A) { egg_pk_exec_body<false>(A); }
-extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_chain_kernel(EggPackedArgs A) { egg_pk_exec_body<true>(A); }
+extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArgs A) { egg_pk_exec_body<false>(A, blockIdx.x); }
+extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_chain_kernel(EggPackedArgs A) { egg_pk_exec_body<true>(A, blockIdx.x); }
+
+// ------------------------------------------------------------------------------------------------
+// Levels, sort and executor of a group in ONE launch (the latency regime: dense islands, groups no more than SIMDs).
+// Against two launches this saves a launch boundary per pass and -- more -- the executor's wait for the slowest group
+// of the walk: a group's projections start the moment ITS levels are sorted.  The phases reuse the dynamic LDS from its
+// base; the three waves the executor does not need exit (a finished wave no longer counts at the workgroup's barriers).
+// (The list kernel stays a launch of its own: its 640-thread workgroups at 42 registers fit three per CU; with this
+// kernel's 85 registers only two would, and the second half of the islands would wait for a whole pass of the first --
+// measured: 3.4 ms per step against 2.4.)
+extern "C" __global__ void __launch_bounds__(256) egg_pk_levexec_kernel(EggPackedArgs A) {
+    const int g = blockIdx.x;
+    if (g >= A.n_groups) return;
+    pk_levels_ooo_body(A, g, 256);
+    __threadfence_block();  // (the sorted list and the chunk descriptors just stored are read back below)
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    __builtin_amdgcn_s_dcache_inv();  // (the chunk descriptors come by scalar loads: written by this launch, a moment ago)
+    egg_pk_exec_body<true>(A, g);
+}
 
 // ------------------------------------------------------------------------------------------------
 // End of a step: post-solve of the last sub-step (L:1690-1693), scatter to particle order, per-atom cell boxes

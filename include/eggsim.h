@@ -243,7 +243,9 @@ int egg_render_particle_texture(egg_handle *h, float *alpha, int64_t cap, int32_
 /* kernels of the packed pipeline (csrc/eggsim_packed.hip), for egg_stats.pk_kernel_ms */
 enum {
     EGG_PK_KIND_BEGIN = 0, EGG_PK_KIND_MID, EGG_PK_KIND_LISTS_FRESH, EGG_PK_KIND_LISTS_STALE, EGG_PK_KIND_LEVELS,
-    EGG_PK_KIND_SORT, EGG_PK_KIND_EXEC, EGG_PK_KIND_END, EGG_PK_KIND_REDUCE, EGG_PK_N_KINDS
+    EGG_PK_KIND_SORT, EGG_PK_KIND_EXEC, EGG_PK_KIND_END, EGG_PK_KIND_REDUCE,
+    EGG_PK_KIND_PASS, /* egg_pk_levexec_kernel: levels + sort + executor of a dense group in one launch */
+    EGG_PK_N_KINDS
 };
 
 /* egg_stats.pk_variants: the kernel a phase of the packed pipeline runs depends on the regime (csrc/eggsim_packed.hip) */
@@ -253,7 +255,8 @@ enum {
     EGG_PK_VARIANT_EXEC = 4,           /* egg_pk_exec_kernel */
     EGG_PK_VARIANT_EXEC_CHAIN = 8,     /* egg_pk_exec_chain_kernel: branch-free projection, executor waves alone on their SIMDs */
     EGG_PK_VARIANT_SORT_LDS = 16,      /* egg_pk_sort_kernel: sorted list assembled in LDS */
-    EGG_PK_VARIANT_SORT_DIRECT = 32    /* egg_pk_sort_direct_kernel */
+    EGG_PK_VARIANT_SORT_DIRECT = 32,   /* egg_pk_sort_direct_kernel */
+    EGG_PK_VARIANT_PASS_FUSED = 64     /* egg_pk_levexec_kernel: out-of-order walk, sort and chain executor of a group in one launch */
 };
 
 /* counters of the device path, cumulative since creation */

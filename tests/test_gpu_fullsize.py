@@ -101,7 +101,7 @@ def test_config3_full_size_every_site_vs_oracle(egg, oracle_mod):
     st = h.stats()
     assert st["packed"][WHITE] >= 1, st  # the packed pipeline, chosen by the host itself
     from egg_fluid_simulation_amd import _ffi
-    assert st["pk_variants"][WHITE] == _ffi.PK_VARIANT_LEVELS_OOO | _ffi.PK_VARIANT_EXEC_CHAIN, st  # dense islands, chip not full
+    assert st["pk_variants"][WHITE] == _ffi.PK_VARIANT_LEVELS_OOO | _ffi.PK_VARIANT_EXEC_CHAIN | _ffi.PK_VARIANT_PASS_FUSED, st  # dense islands, chip not full: one launch per pass
     assert st["n_tiles"][WHITE] == n // overlap
     _check_budget_not_binding(st)
     # 16 sites per chunk: the yolk type's own 0.05 (16 * 60)^2 would not bind either, but the chunk carries the scene's N anyway

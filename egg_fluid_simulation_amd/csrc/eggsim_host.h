@@ -236,6 +236,8 @@ struct System {  // one particle type
     DevBuf<unsigned char> d_scratch;
     std::vector<LaunchClass> classes;
     int margin = 2;
+    bool padded = false;   // the current claims carry motion padding or extra margins (see the commit in do_step)
+    int since_tiling = 0;  // committed steps on the current tiling
     int single_tile = 0;  // exact-budget mode: everything in one tile
     int uncut_streak = 0;
     double list_factor = 6.0;  // visit-list capacity per particle, grows on overflow

@@ -97,6 +97,8 @@ int retile(egg_handle *h, int which) {
         // damping); the step kernel reports every atom's largest particle travel per direction
         const bool have_motion = s.disp_valid && s.disp.size() == 4 * na;
         s.swept = false;
+        s.padded = s.margin > h->opt_margin;
+        s.since_tiling = 0;
         for (size_t k = 0; k < na; ++k) {
             const Box &b = s.aabb[k];
             const Batch &B = h->batches[(size_t)s.atoms[k].batch];
@@ -124,6 +126,7 @@ int retile(egg_handle *h, int which) {
                 }
                 side[q] = std::max(mk, (int)std::min(4096.0, std::ceil(1.25 * travel / cell)));
                 s.swept |= side[q] > mk;
+                s.padded |= side[q] > m;
             }
             claim[k] = Box{b.lo_x - side[1], b.lo_y - side[3], b.hi_x + side[0], b.hi_y + side[2]};
         }
@@ -511,9 +514,9 @@ int retile(egg_handle *h, int which) {
             if (pc.levels_ooo) {
                 // the levels of a tile's stream live in LDS: room for 24 pairs per particle (a dense island's first
                 // steps: ~20), more after a launch that needed more, never more than the stream itself can hold
-                // (once steps have run: a quarter more than the longest list any tile had in the last step -- a fused pass keeps
+                // (once steps have run: half as much again as the longest list any tile had in the last step -- a fused pass keeps
                 // its LDS small enough for four islands per CU that way; a launch that needs more says so and is re-run)
-                const size_t guess = s.pk_seen_list ? (size_t)(s.pk_seen_list * 5 / 4 + 256) : (size_t)24 * lc.nmax;
+                const size_t guess = s.pk_seen_list ? (size_t)(s.pk_seen_list * 3 / 2 + 512) : (size_t)24 * lc.nmax;
                 pc.lev_lds_cap = (int)std::min<size_t>((size_t)pc.scap, std::max<size_t>(guess, s.pk_lev_lds_min));
                 pc.lev_lds_cap = (pc.lev_lds_cap + 7) & ~7;
                 pc.levels_threads = 64 * std::min(16, std::max((h->opt_tune & 8) ? 8 : 4, max_tiles_in_group));  // a wave per tile, at least four per group (eight were 10 % slower)

@@ -352,12 +352,13 @@ def main():
         traffic, valu, traffic_source = None, None, None
         for cf in COUNTER_FILES if world == 1 else []:
             try:
-                c = json.load(open(cf)).get("%d_%d" % (args.batches, args.overlap))
+                whole = json.load(open(cf))
+                c = whole.get("%d_%d" % (args.batches, args.overlap))
             except Exception:
-                c = None
+                whole, c = {}, None
             if c:
                 traffic, valu = c.get("hbm_bytes_per_step"), c.get("valu")
-                traffic_source = {"file": os.path.relpath(cf, ROOT), "commit": git_commit_of(cf),
+                traffic_source = {"file": os.path.relpath(cf, ROOT), "commit": git_commit_of(cf) or (whole.get("_source") or {}).get("code_commit"),
                                   "how": "scripts/collect_counters.sh (rocprofv3 --pmc, one pass per counter set, summed over every launch of a step; 2 x FETCH_SIZE + WRITE_SIZE); NOT measured in this run"}
                 break
         out = {

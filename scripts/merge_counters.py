@@ -19,4 +19,11 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "cnt_*", "summary.jso
     overlap = int(a[a.index("--overlap") + 1]) if "--overlap" in a else 4
     out["%d_%d" % (batches, overlap)] = d
     print("merged", f, "->", "%d_%d" % (batches, overlap))
+import subprocess
+try:  # the commit the counters were taken at (the GPU box has no .git: stamped here, when the summaries are merged)
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "egg_fluid_simulation_amd"], capture_output=True, text=True).stdout.strip())
+    out["_source"] = {"code_commit": head + ("+uncommitted changes" if dirty else ""), "how": "scripts/collect_counters.sh on one MI355X, merged by scripts/merge_counters.py"}
+except Exception:
+    pass
 json.dump(out, open(dst, "w"), indent=1)

@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(64) chain(int levels, const double2 *gwr, unsi
     for (int i = lane; i < 64 * 3 * 4; i += 64) ring[i] = make_double2(0.0263, 16.0);
     __syncthreads();
     const double overlap = 2.0, compliance = 36.0, eps = 1e-8;
-    int ga = lane * 2, gb = lane * 2 + 1;
+    int ga = MODE == 3 ? lane : lane * 2, gb = MODE == 3 ? 64 + lane : lane * 2 + 1;
     double2 wa = gwr[ga], wb = gwr[gb];
     double2 pc = make_double2(egg_rcp_refined((wa.x + wb.x) + compliance), overlap * (wa.y + wb.y));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -39,9 +39,14 @@ __global__ void __launch_bounds__(64) chain(int levels, const double2 *gwr, unsi
         lpos[store ? ga : 1344 + lane] = pa;
         lpos[store ? gb : 1344 + lane] = pb;
         // next level: other particles (a dependent chain through LDS: b of this level is a of the next lane's)
-        ga = (ga + 129) % 1280;
-        gb = (gb + 131) % 1280;
-        if (ga == gb) gb = (gb + 1) % 1280;
+        if (MODE == 3) {  // consecutive 16-byte slots per lane group: no LDS bank conflicts at all
+            ga = (ga + 128) % 1280;
+            gb = (gb + 128) % 1280;
+        } else {  // scattered slots, like the particles of a sorted pair list
+            ga = (ga + 129) % 1280;
+            gb = (gb + 131) % 1280;
+            if (ga == gb) gb = (gb + 1) % 1280;
+        }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (lane == 0) out[blockIdx.x] = t1 - t0;
@@ -74,5 +79,6 @@ int main() {
     printf("%-60s %10.1f %10.1f\n", "chain only (constants in registers)", run<0>(1, 2000, gwr), run<0>(512, 2000, gwr));
     printf("%-60s %10.1f %10.1f\n", "chain + 3 x 16 B prepared record from an LDS ring", run<1>(1, 2000, gwr), run<1>(512, 2000, gwr));
     printf("%-60s %10.1f %10.1f\n", "chain + 2 global gathers + reciprocal (unpipelined)", run<2>(1, 2000, gwr), run<2>(512, 2000, gwr));
+    printf("%-60s %10.1f %10.1f\n", "chain only, conflict-free LDS slots", run<3>(1, 2000, gwr), run<3>(512, 2000, gwr));
     return 0;
 }

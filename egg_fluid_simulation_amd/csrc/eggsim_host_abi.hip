@@ -866,6 +866,7 @@ int egg_set_option(egg_handle *h, int option, double value) {
             return EGG_OK;
         case EGG_OPT_LEVEL_WALK:
             if (!(value == 0 || value == 1 || value == 2)) return fail(h, EGG_ERR_INVALID_ARGUMENT, "level walk must be 0 (by regime), 1 (in order) or 2 (out of order)");
+            if (value == 2 && !h->lds_lane_ordered) return fail(h, EGG_ERR_UNSUPPORTED, "the out-of-order level walk needs same-address LDS atomics served in lane order; this device's probe failed");
             h->opt_level_walk = (int)value;
             h->sys[0].tiling_dirty = h->sys[1].tiling_dirty = true;
             return EGG_OK;

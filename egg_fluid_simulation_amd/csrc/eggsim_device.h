@@ -173,6 +173,7 @@ struct EggPackedArgs {
     int32_t n_substeps, n_collision_steps;
     int32_t pass_seq, substep, stale;  // of the launch
     int32_t tune;              // developer experiments (EGGSIM_TUNE), 0 in normal operation
+    uint32_t *simd_claims;     // [4096] per compute unit: SIMDs taken by executor waves of egg_pk_levexec_kernel right now
     int32_t lev_lds_cap;       // out-of-order walk: entries of a tile's stream whose levels fit the LDS array of the launch
     EggStatus *status, *status_next;
 };
@@ -195,6 +196,10 @@ static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int us
     b += egg_align16((size_t)stage_cap * n * 2);  // partners kept by the counting pass
     return b;
 }
+// egg_pk_levexec_kernel: the ring of ready-made pair records between its helper wave and its executor wave:
+// EGG_PK_RING chunks x 64 lanes x (8 B addresses + 3 x 16 B constants)
+#define EGG_PK_RING 8
+#define EGG_PK_RING_BYTES (EGG_PK_RING * 64 * 56)
 // dynamic LDS of egg_pk_levels_mr16 (the in-order walk): level histogram, last level and a stamp word per particle of the
 // group, one stream window per sub-wave of 16 lanes
 static inline size_t egg_pk_levels_mr_lds_bytes(int lev_cap, int group_particles, int threads) {

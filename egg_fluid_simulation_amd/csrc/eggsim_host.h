@@ -305,6 +305,7 @@ struct egg_handle {
     bool packed_auto = false;  // the automatic choice, made when the white tiles are formed
     int opt_tune = 0;         // EGGSIM_TUNE: developer experiments inside the packed kernels
     int opt_level_walk = 0;   // packed pipeline, EGG_OPT_LEVEL_WALK: 0 by regime, 1 always in order, 2 out of order wherever the probe allows
+    DevBuf<uint32_t> simd_claims;   // egg_pk_levexec_kernel: which SIMDs of a compute unit run an executor wave (zero between launches)
     bool lds_lane_ordered = false;  // one ds_add_rtn serves same-address lanes in ascending lane order (probed at create)
     int opt_packed = -1;      // packed pipeline: -1 automatic (large scenes), 0 never, 1 every eligible class
     int opt_group_particles = 0;  // particles one wave of the packed executor keeps in LDS (16 B each): 0 = by scene size (retile), at most 1280

@@ -114,6 +114,10 @@ int egg_create(const egg_config *white, const egg_config *yolk, int device, egg_
         }
         const hipError_t pe = hipGetLastError();
         h->lds_lane_ordered = host_bad == 0;
+        if (h->simd_claims.reserve(4096, false, 0) != hipSuccess || hipMemset(h->simd_claims.p, 0, 4096 * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            h->lds_lane_ordered = false;  // (without the table the fused pass is not used either: it is chosen with the out-of-order walk)
+        }
         if (getenv("EGGSIM_DEBUG")) fprintf(stderr, "eggsim: LDS atomic lane-order probe: %llu mismatches (%s)\n", host_bad, hipGetErrorString(pe));
     }
     if (const char *e_gp = getenv("EGGSIM_GROUP_PARTICLES")) h->opt_group_particles = std::max(1, atoi(e_gp));

@@ -205,6 +205,7 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.status_next = d_stat(s, s.parity ^ 1);
     A.tune = h->opt_tune;
     A.lev_lds_cap = pc.lev_lds_cap;
+    A.simd_claims = h->simd_claims.p;
 }
 
 int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
@@ -671,6 +672,9 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
                         w, (long long)h->stats.steps, st.visits[55], st.visits[56], st.visits[57], st.visits[58], st.visits[59], st.visits[60], st.visits[61], st.visits[62], st.rounds, st.max_level);
             if (getenv("EGGSIM_DEBUG") && !s.pk.empty()) {
                 fprintf(stderr, "   group 0 wave 0: %llu turns; cycles waiting for the batch's entries %llu, in the batch set-up %llu, in the turns %llu\n", st.visits[38], st.visits[36], st.visits[39], st.visits[37]);
+                fprintf(stderr, "   executor of group 0: %llu cycles for %llu chunks = %.1f per chunk; slowest group %.1f per chunk\n", st.visits[30], st.visits[31],
+                        (double)st.visits[30] / (double)std::max<unsigned long long>(st.visits[31], 1), (double)st.visits[32] / 16.0);
+                fprintf(stderr, "   executor waves on SIMD 0 / 1 / 2 (all passes of the step): %llu %llu %llu; without a SIMD of their own: %llu\n", st.visits[33], st.visits[34], st.visits[35], st.visits[29]);
                 fprintf(stderr, "   groups by total cycles (25k buckets):");
                 for (int k = 0; k < 15; ++k) fprintf(stderr, " %llu", st.visits[40 + k]);
                 fprintf(stderr, "\n");

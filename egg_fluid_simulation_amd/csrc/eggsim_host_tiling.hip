@@ -539,7 +539,7 @@ int retile(egg_handle *h, int which) {
                 continue;
             }
             if (pc.fused_pass) {
-                pc.lds_pass = std::max(pc.lds_levels, pc.lds_exec + 64 * 16);
+                pc.lds_pass = std::max(pc.lds_levels, pc.lds_exec + 64 * 16 + (size_t)EGG_PK_RING_BYTES);
                 if (pc.lds_pass > h->lds_limit) pc.fused_pass = 0;
             }
             pc.sort_cap = (int)sort_words;

@@ -1041,7 +1041,7 @@ template <bool PREDICATED>
 __device__ __forceinline__ void egg_pk_exec_body(const EggPackedArgs &A, const int g) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (g >= A.n_groups) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int nch = A.grp_nchunks[g];
     if (nch <= 0) return;  // nothing to do: positions stay as they are
     const int4 gg = ((const int4 *)A.grp_geo)[g];
@@ -1100,34 +1100,118 @@ __device__ __forceinline__ void egg_pk_exec_body(const EggPackedArgs &A, const i
     }
 #pragma unroll
     for (int u = 0; u < D_PC; ++u) pc[u] = pair_constants(wa[u], wb[u]);
-    for (int c0 = 0; c0 < nch; c0 += R) {
+    if (PREDICATED) {
+        // One wave alone on its SIMD issues one instruction at a time, and every instruction between the last add of a
+        // level and the first subtraction of the next is time on the island's dependent chain.  The order of a turn is
+        // therefore fixed by hand (scheduling barriers; left alone the compiler put the ~35 instructions of the look-ahead
+        // stages between a level's last add and its stores):
+        //   stores of chunk c-1 | loads of chunk c | the look-ahead stages, in the shadow of that LDS turn-around |
+        //   the projection of chunk c (the descriptor's scalar load behind its first instruction: a scalar load in
+        //   flight would be waited for together with the positions)
+        // (a value that passed through EGG_PIN is computed neither earlier nor later than that point: pure arithmetic is
+        // otherwise free to move across a scheduling barrier, and to sink into the next turn)
+#define EGG_PIN(x) __asm__ volatile("" : "+v"(x))
+        typedef double egg_v2d __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) egg_v2d egg_lds_d2;  // (32-bit LDS addresses: a select between two of them is one instruction)
+        egg_lds_d2 *const lp = (egg_lds_d2 *)lpos;
+        egg_lds_d2 *const spare = lp + np + lane;  // lanes with nothing to store write their own spare slot
+        double md2s[R];
 #pragma unroll
-        for (int u = 0; u < R; ++u) {
-            const int c = c0 + u;
-            rec[(u + D_REC) & (R - 1)] = load_rec(c + D_REC, dsc[(u + D_REC) & (R - 1)]);
-            dsc[(u + D_DSC) & (R - 1)] = load_desc(c + D_DSC);
-            wa[(u + D_WR) & (R - 1)] = gwr[rec[(u + D_WR) & (R - 1)] & 0x7FFFu];
-            wb[(u + D_WR) & (R - 1)] = gwr[(rec[(u + D_WR) & (R - 1)] >> 16) & 0x7FFFu];
-            pc[(u + D_PC) & (R - 1)] = pair_constants(wa[(u + D_PC) & (R - 1)], wb[(u + D_PC) & (R - 1)]);
-            const uint32_t r0 = rec[u];
-            if (PREDICATED) {
+        for (int u = 0; u < D_PC; ++u) md2s[u] = pc[u].y * pc[u].y;
+        egg_lds_d2 *qa = lp + (rec[0] & 0x7FFFu), *qb = lp + ((rec[0] >> 16) & 0x7FFFu);
+        uint32_t flags = rec[0] & 0x80008000u;  // bit 31: the lane has a pair, bit 15: the pair takes the reference path
+        // (every load of the prologue is waited for HERE: with loads pending on entry the compiler's wait-count pass cannot
+        // tell how many are in flight at the loop head and waits for all of them -- including the ones a turn old -- once
+        // per trip of the unrolled loop)
+#pragma unroll
+        for (int u = 0; u < D_REC; ++u) EGG_PIN(rec[u]);
+#pragma unroll
+        for (int u = 0; u < D_WR; ++u) {
+            EGG_PIN(wa[u].x);
+            EGG_PIN(wa[u].y);
+            EGG_PIN(wb[u].x);
+            EGG_PIN(wb[u].y);
+        }
+        for (int c0 = 0; c0 < nch; c0 += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int c = c0 + u;
                 // (lanes without a pair read particle 0 of the group and write nothing)
-                const bool has_pair = (r0 >> 31) != 0;
-                const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
-                double2 pa = lpos[ga], pb = lpos[gb];
+                const egg_v2d va = *qa, vb = *qb;
+                double2 pa = make_double2(va.x, va.y), pb = make_double2(vb.x, vb.y);
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t r1 = rec[(u + 1) & (R - 1)];
+                double2 a1 = wa[(u + D_PC) & (R - 1)], b1 = wb[(u + D_PC) & (R - 1)];
+                EGG_PIN(r1);
+                EGG_PIN(a1.x);
+                EGG_PIN(a1.y);
+                EGG_PIN(b1.x);
+                EGG_PIN(b1.y);
+                rec[(u + D_REC) & (R - 1)] = load_rec(c + D_REC, dsc[(u + D_REC) & (R - 1)]);
+                wa[(u + D_WR) & (R - 1)] = gwr[rec[(u + D_WR) & (R - 1)] & 0x7FFFu];
+                wb[(u + D_WR) & (R - 1)] = gwr[(rec[(u + D_WR) & (R - 1)] >> 16) & 0x7FFFu];
+                wa[(u + D_PC) & (R - 1)] = a1;
+                wb[(u + D_PC) & (R - 1)] = b1;
+                double2 pc1 = pair_constants(a1, b1);
+                double md21 = pc1.y * pc1.y;
+                egg_lds_d2 *qa1 = lp + (r1 & 0x7FFFu), *qb1 = lp + ((r1 >> 16) & 0x7FFFu);
+                uint32_t flags1 = r1 & 0x80008000u;
+                EGG_PIN(pc1.x);
+                EGG_PIN(pc1.y);
+                EGG_PIN(md21);
+                EGG_PIN(qa1);
+                EGG_PIN(qb1);
+                EGG_PIN(flags1);
+                pc[(u + D_PC) & (R - 1)] = pc1;
+                md2s[(u + D_PC) & (R - 1)] = md21;
+                __builtin_amdgcn_sched_barrier(0);
                 const bool store = project_pair_predicated(
-                    [&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; }, has_pair,
-                    (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], pc[u], overlap, compliance, eps);
-                // unconditional stores: lanes with nothing to store write their own spare slot behind the particles
-                lpos[store ? ga : np + lane] = pa;
-                lpos[store ? gb : np + lane] = pb;
-            } else if (r0 >> 31) {
-                const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
-                double2 pa = lpos[ga], pb = lpos[gb];
-                project_pair<true>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
-                                   (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], pc[u], overlap, compliance, eps);
-                lpos[ga] = pa;
-                lpos[gb] = pb;
+                    [&]() { return A.atom_batch[A.pk_atom[p0 + (int)(qa - lp)]] == A.atom_batch[A.pk_atom[p0 + (int)(qb - lp)]]; },
+                    [&]() {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dsc[(u + D_DSC) & (R - 1)] = load_desc(c + D_DSC);
+                    },
+                    [&](double2 &wra, double2 &wrb) {
+                        wra = wa[u];
+                        wrb = wb[u];
+                    },
+                    (flags >> 31) != 0, (flags & 0x8000u) != 0, pa, pb, wa[u].x, wb[u].x, (wa[u].x + wb[u].x) + compliance, pc[u], md2s[u], overlap,
+                    compliance, eps);
+                {
+                    egg_v2d oa, ob;
+                    oa.x = pa.x;
+                    oa.y = pa.y;
+                    ob.x = pb.x;
+                    ob.y = pb.y;
+                    *(store ? qa : spare) = oa;
+                    *(store ? qb : spare) = ob;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                qa = qa1;
+                qb = qb1;
+                flags = flags1;
+            }
+        }
+#undef EGG_PIN
+    } else {
+        for (int c0 = 0; c0 < nch; c0 += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int c = c0 + u;
+                rec[(u + D_REC) & (R - 1)] = load_rec(c + D_REC, dsc[(u + D_REC) & (R - 1)]);
+                dsc[(u + D_DSC) & (R - 1)] = load_desc(c + D_DSC);
+                wa[(u + D_WR) & (R - 1)] = gwr[rec[(u + D_WR) & (R - 1)] & 0x7FFFu];
+                wb[(u + D_WR) & (R - 1)] = gwr[(rec[(u + D_WR) & (R - 1)] >> 16) & 0x7FFFu];
+                pc[(u + D_PC) & (R - 1)] = pair_constants(wa[(u + D_PC) & (R - 1)], wb[(u + D_PC) & (R - 1)]);
+                const uint32_t r0 = rec[u];
+                if (r0 >> 31) {
+                    const int ga = (int)(r0 & 0x7FFFu), gb = (int)((r0 >> 16) & 0x7FFFu);
+                    double2 pa = lpos[ga], pb = lpos[gb];
+                    project_pair<true>([&]() { return A.atom_batch[A.pk_atom[p0 + ga]] == A.atom_batch[A.pk_atom[p0 + gb]]; },
+                                       (r0 & 0x8000u) != 0, pa, pb, wa[u], wb[u], pc[u], overlap, compliance, eps);
+                    lpos[ga] = pa;
+                    lpos[gb] = pb;
+                }
             }
         }
     }
@@ -1137,22 +1221,289 @@ extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_kernel(EggPackedArg
 extern "C" __global__ void __launch_bounds__(64) egg_pk_exec_chain_kernel(EggPackedArgs A) { egg_pk_exec_body<true>(A, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
+// The executor of the fused pass, split over TWO waves on two SIMDs.
+//
+// A lone wave issues one instruction every ~4.5-5.4 cycles whatever it is, so on the island's dependent chain every
+// instruction counts -- and a third of egg_pk_exec_body's turn (37 of 99 instructions: chunk descriptors, entries,
+// the gathers of the inverse masses, the pairs' reciprocals and minimum distances, LDS addresses) has nothing to do with
+// the chain.  Here a HELPER wave does all of that, a few chunks ahead, and leaves per lane and chunk a ready-made record
+// in an LDS ring: the two LDS addresses (+ flags), (inverse masses), (reciprocal of the divisor, minimum distance),
+// (divisor, minimum distance squared).  The EXECUTOR's turn is then: two stores, two position loads, four record loads
+// for the next chunk in the shadow of that LDS turn-around, the projection.  Measured on the bare chain
+// (scripts/micro/chain_floor.hip): 420 cycles per level for the chain alone, 475-515 as this consumer, 635 for
+// egg_pk_exec_body in place.
+// Flow control through two LDS words: `produced` (chunks the helper has finished; it writes the records, then the
+// word -- one wave's LDS operations execute in order) and `consumed` (records the executor has read, published every
+// fourth chunk); the helper never runs more than EGG_PK_RING chunks ahead of `consumed`.
+typedef double egg_v2d __attribute__((ext_vector_type(2)));
+typedef uint32_t egg_v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) egg_v2d egg_lds_v2d;
+typedef __attribute__((address_space(3))) uint32_t egg_lds_u32;
+struct PkRing {
+    egg_v2d *a, *c, *d;  // [EGG_PK_RING][64] (wa, wb) | (1 / divisor refined, minimum distance) | (divisor, minimum distance^2)
+    egg_v2u *q;          // [EGG_PK_RING][64] LDS address of a | has pair | slow << 1, LDS address of b
+    // (LDS pointers by type: through a generic pointer a volatile access becomes a FLAT instruction, which reaches the LDS
+    // by another path than the ds_ instructions around it -- and the records must land before the word that announces them)
+    volatile egg_lds_u32 *produced, *consumed;
+};
+__device__ __forceinline__ PkRing pk_ring_at(unsigned char *base, uint32_t *produced, uint32_t *consumed) {
+    PkRing r;
+    r.a = (egg_v2d *)base;
+    r.c = r.a + EGG_PK_RING * 64;
+    r.d = r.c + EGG_PK_RING * 64;
+    r.q = (egg_v2u *)(r.d + EGG_PK_RING * 64);
+    r.produced = (volatile egg_lds_u32 *)produced;
+    r.consumed = (volatile egg_lds_u32 *)consumed;
+    return r;
+}
+
+__device__ __forceinline__ void egg_pk_exec_helper(const EggPackedArgs &A, const int g, const PkRing ring) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int nch = A.grp_nchunks[g];
+    if (nch <= 0) return;
+    const int nch_pad = (nch + 7) & ~7;  // (the executor's loop is unrolled by eight: the chunks behind the list are empty ones)
+    const int4 gg = ((const int4 *)A.grp_geo)[g];
+    const int p0 = __builtin_amdgcn_readfirstlane(gg.z);
+    egg_lds_v2d *const lp = (egg_lds_v2d *)smem;
+    const double2 *gwr = (const double2 *)A.pk_wr + p0;
+    const uint32_t *sorted = A.sorted + (size_t)g * A.sort_cap;
+    typedef const __attribute__((address_space(4))) uint32_t egg_const_u32;
+    egg_const_u32 *kchunks = (egg_const_u32 *)(uintptr_t)(A.chunks + (size_t)g * A.chunk_cap);
+    const double overlap = A.overlap_factor, compliance = A.collision_compliance;
+    auto load_desc = [&](int c) -> uint32_t { return kchunks[min(c, nch - 1)]; };
+    auto load_rec = [&](int c, uint32_t desc) -> uint32_t {
+        const uint32_t start = desc & 0x3FFFFFFu, cnt = (c < nch) ? (desc >> 26) + 1u : 0u;
+        const uint32_t w = sorted[start + (uint32_t)lane];
+        return ((uint32_t)lane < cnt) ? w : 0u;
+    };
+    constexpr int R = 8, D_DSC = 6, D_REC = 4, D_WR = 2;  // every stage two chunks ahead of its consumer, as in egg_pk_exec_body
+    uint32_t dsc[R], rec[R];
+    double2 wa[R], wb[R];
+#pragma unroll
+    for (int u = 0; u < D_DSC; ++u) dsc[u] = load_desc(u);
+#pragma unroll
+    for (int u = 0; u < D_REC; ++u) rec[u] = load_rec(u, dsc[u]);
+#pragma unroll
+    for (int u = 0; u < D_WR; ++u) {
+        wa[u] = gwr[rec[u] & 0x7FFFu];
+        wb[u] = gwr[(rec[u] >> 16) & 0x7FFFu];
+    }
+    int room = EGG_PK_RING;  // chunks below this index may be written: consumed + EGG_PK_RING
+    for (int k0 = 0; k0 < nch_pad; k0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int k = k0 + u;
+            rec[(u + D_REC) & (R - 1)] = load_rec(k + D_REC, dsc[(u + D_REC) & (R - 1)]);
+            dsc[(u + D_DSC) & (R - 1)] = load_desc(k + D_DSC);
+            wa[(u + D_WR) & (R - 1)] = gwr[rec[(u + D_WR) & (R - 1)] & 0x7FFFu];
+            wb[(u + D_WR) & (R - 1)] = gwr[(rec[(u + D_WR) & (R - 1)] >> 16) & 0x7FFFu];
+            const uint32_t r0 = rec[u];
+            const double2 a = wa[u], b = wb[u];
+            egg_v2d ra, rc, rd;
+            ra.x = a.x;
+            ra.y = b.x;
+            const double divisor = (a.x + b.x) + compliance;
+            rc.x = egg_rcp_refined(divisor);
+            rc.y = overlap * (a.y + b.y);
+            rd.x = divisor;
+            rd.y = rc.y * rc.y;
+            egg_v2u rq;  // (lanes without a pair: particle 0 of the group, read and never stored)
+            rq.x = (uint32_t)(uintptr_t)(lp + (r0 & 0x7FFFu)) | (r0 >> 31) | ((r0 >> 14) & 2u);
+            rq.y = (uint32_t)(uintptr_t)(lp + ((r0 >> 16) & 0x7FFFu));
+            if (k >= room) {  // the ring is full: wait for the executor
+                for (;;) {
+                    room = (int)__builtin_amdgcn_readfirstlane(*ring.consumed) + EGG_PK_RING;
+                    if (k < room) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            const int slot = (u & (EGG_PK_RING - 1)) * 64 + lane;
+            ring.a[slot] = ra;
+            ring.c[slot] = rc;
+            ring.d[slot] = rd;
+            ring.q[slot] = rq;
+            __asm__ volatile("" ::: "memory");
+            *ring.produced = (uint32_t)(k + 1);
+            __asm__ volatile("" ::: "memory");
+        }
+    }
+}
+
+__device__ __forceinline__ void egg_pk_exec_consumer(const EggPackedArgs &A, const int g, const PkRing ring) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int nch = A.grp_nchunks[g];
+    if (nch <= 0) return;  // nothing to do: positions stay as they are
+    const int nch_pad = (nch + 7) & ~7;
+    const int4 gg = ((const int4 *)A.grp_geo)[g];
+    const int p0 = __builtin_amdgcn_readfirstlane(gg.z), np = __builtin_amdgcn_readfirstlane(gg.w);
+    double2 *lpos = (double2 *)smem;
+    double2 *gpos = (double2 *)A.pk_pos + p0;
+    for (int i0 = 0; i0 < np; i0 += 512) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gpos[min(i0 + 64 * u + lane, np - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lpos[min(i0 + 64 * u + lane, np - 1)] = v[u];
+    }
+    const double overlap = A.overlap_factor, compliance = A.collision_compliance, eps = A.eps;
+    egg_lds_v2d *const lp = (egg_lds_v2d *)smem;
+    egg_lds_v2d *const spare = lp + np + lane;  // lanes with nothing to store write their own spare slot
+    int seen = 0;  // chunks the helper is known to have finished
+    auto wait_for = [&](int chunk) {
+        if (__builtin_expect(seen <= chunk, 0)) {
+            for (;;) {
+                seen = (int)__builtin_amdgcn_readfirstlane(*ring.produced);
+                if (seen > chunk) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __asm__ volatile("" ::: "memory");
+    };
+    wait_for(0);
+    egg_v2d ra = ring.a[lane], rc = ring.c[lane], rd = ring.d[lane];
+    egg_v2u rq = ring.q[lane];
+    for (int c0 = 0; c0 < nch_pad; c0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            egg_lds_v2d *const qa = (egg_lds_v2d *)(uintptr_t)(rq.x & ~15u), *const qb = (egg_lds_v2d *)(uintptr_t)rq.y;
+            const bool has_pair = (rq.x & 1u) != 0, slow = (rq.x & 2u) != 0;
+            const egg_v2d va = *qa, vb = *qb;
+            __builtin_amdgcn_sched_barrier(0);
+            // the next chunk's record, in the shadow of the loads above
+            egg_v2d ra1 = ra, rc1 = rc, rd1 = rd;
+            egg_v2u rq1 = rq;
+            if (u < 7 || c + 1 < nch_pad) {
+                wait_for(c + 1);
+                const int slot = ((u + 1) & (EGG_PK_RING - 1)) * 64 + lane;
+                ra1 = ring.a[slot];
+                rc1 = ring.c[slot];
+                rd1 = ring.d[slot];
+                rq1 = ring.q[slot];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double2 pa = make_double2(va.x, va.y), pb = make_double2(vb.x, vb.y);
+            const bool store = project_pair_predicated(
+                [&]() { return A.atom_batch[A.pk_atom[p0 + (int)(qa - lp)]] == A.atom_batch[A.pk_atom[p0 + (int)(qb - lp)]]; }, []() {},
+                [&](double2 &wra, double2 &wrb) {  // (the rare pair on the reference path fetches its radii itself)
+                    wra = ((const double2 *)A.pk_wr)[p0 + (int)(qa - lp)];
+                    wrb = ((const double2 *)A.pk_wr)[p0 + (int)(qb - lp)];
+                },
+                has_pair, slow, pa, pb, ra.x, ra.y, rd.x, make_double2(rc.x, rc.y), rd.y, overlap, compliance, eps);
+            {
+                egg_v2d oa, ob;
+                oa.x = pa.x;
+                oa.y = pa.y;
+                ob.x = pb.x;
+                ob.y = pb.y;
+                *(store ? qa : spare) = oa;
+                *(store ? qb : spare) = ob;
+            }
+            if (u == 3 || u == 7) {  // records up to chunk c + 1 are in registers: their slots may be written again
+                __asm__ volatile("" ::: "memory");
+                *ring.consumed = (uint32_t)(c + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ra = ra1;
+            rc = rc1;
+            rd = rd1;
+            rq = rq1;
+        }
+    }
+    for (int i = lane; i < np; i += 64) gpos[i] = lpos[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Levels, sort and executor of a group in ONE launch (the latency regime: dense islands, groups no more than SIMDs).
 // Against two launches this saves a launch boundary per pass and -- more -- the executor's wait for the slowest group
 // of the walk: a group's projections start the moment ITS levels are sorted.  The phases reuse the dynamic LDS from its
-// base; the three waves the executor does not need exit (a finished wave no longer counts at the workgroup's barriers).
+// base; the waves the executor does not need exit (a finished wave no longer counts at the workgroup's barriers).
 // (The list kernel stays a launch of its own: its 640-thread workgroups at 42 registers fit three per CU; with this
-// kernel's 85 registers only two would, and the second half of the islands would wait for a whole pass of the first --
+// kernel's registers only two would, and the second half of the islands would wait for a whole pass of the first --
 // measured: 3.4 ms per step against 2.4.)
 extern "C" __global__ void __launch_bounds__(256) egg_pk_levexec_kernel(EggPackedArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
     pk_levels_ooo_body(A, g, 256);
     __threadfence_block();  // (the sorted list and the chunk descriptors just stored are read back below)
+    // Which waves become the executor and its helper?  Two groups share a compute unit, each with a wave on every SIMD.
+    // An executor wave is bound by its own instruction issue, so two of them on one SIMD run at half speed each -- with
+    // "wave 0" for everybody that happened on a quarter of the compute units (780-830 cycles per level there against
+    // 640).  So the executor and helper waves of a compute unit claim their SIMDs in a per-unit word in global memory:
+    // a group takes SIMDs no other group's executor or helper is on, and gives them back when it is done.
+    __shared__ uint32_t simd_of_wave[4];
+    __shared__ int exec_wave_s, help_wave_s;
+    __shared__ uint32_t claim_key_s, claim_exec_s, claim_help_s;
+    __shared__ uint32_t ring_produced, ring_consumed;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_REG_HW_ID: SIMD_ID 5:4, CU_ID 11:8, SH_ID 12, SE_ID 15:13
+    if ((threadIdx.x & 63) == 0) simd_of_wave[wave] = (hw_id >> 4) & 3u;
     __syncthreads();
-    if (threadIdx.x >= 64) return;
-    __builtin_amdgcn_s_dcache_inv();  // (the chunk descriptors come by scalar loads: written by this launch, a moment ago)
-    egg_pk_exec_body<true>(A, g);
+    if (threadIdx.x == 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID: XCC_ID 3:0
+        const uint32_t key = ((hw_id >> 8) & 0xFFu) | (xcc << 8);
+        uint32_t present = 0;
+        for (int w = 0; w < 4; ++w) present |= 1u << simd_of_wave[w];
+        uint32_t got[2] = {0, 0};
+        uint32_t seen = __hip_atomic_load(&A.simd_claims[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int role = 0; role < 2; ++role)
+            for (int tries = 0; tries < 8; ++tries) {
+                const uint32_t free_simds = present & ~seen & ~got[0] & 0xFu;
+                if (!free_simds) break;  // every SIMD we have a wave on is taken (more than two groups on the unit): share one, unclaimed
+                const uint32_t want = free_simds & (0u - free_simds);
+                const uint32_t prev = atomicOr(&A.simd_claims[key], want);
+                seen = prev | want;
+                if (!(prev & want)) {
+                    got[role] = want;
+                    break;
+                }
+            }
+        int ew = -1, hw = -1;
+        for (int w = 0; w < 4; ++w) {
+            if (got[0] && ew < 0 && (1u << simd_of_wave[w]) == got[0]) ew = w;
+            if (got[1] && hw < 0 && (1u << simd_of_wave[w]) == got[1]) hw = w;
+        }
+        if (ew < 0) ew = 0;
+        if (hw < 0 || hw == ew) hw = (ew + 1) & 3;
+        exec_wave_s = ew;
+        help_wave_s = hw;
+        claim_key_s = key;
+        claim_exec_s = got[0];
+        claim_help_s = got[1];
+        ring_produced = 0;
+        ring_consumed = 0;
+    }
+    __syncthreads();
+    const int np = __builtin_amdgcn_readfirstlane(((const int4 *)A.grp_geo)[g].w);
+    const PkRing ring = pk_ring_at(smem + egg_align16((size_t)(np + 64) * 16), &ring_produced, &ring_consumed);
+    if (wave == help_wave_s) {
+        __builtin_amdgcn_s_dcache_inv();  // (the chunk descriptors come by scalar loads: written by this launch, a moment ago)
+        egg_pk_exec_helper(A, g, ring);
+        if ((threadIdx.x & 63) == 0 && claim_help_s) atomicAnd(&A.simd_claims[claim_key_s], ~claim_help_s);
+        return;
+    }
+    if (wave != exec_wave_s) return;
+    EGG_STAMP(E0);
+    egg_pk_exec_consumer(A, g, ring);
+    if ((threadIdx.x & 63) == 0 && claim_exec_s) atomicAnd(&A.simd_claims[claim_key_s], ~claim_exec_s);
+#ifdef EGG_PROFILE
+    __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    EGG_STAMP(E1);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long nch = (unsigned long long)max(A.grp_nchunks[g], 1);
+        if (g == 0) {
+            A.status->visits[30] = E1 - E0;
+            A.status->visits[31] = nch;
+        }
+        atomicMax(&A.status->visits[32], (E1 - E0) * 16ull / nch);  // slowest group, cycles per chunk x 16
+        const uint32_t simd = (hw_id >> 4) & 3u;
+        if (simd < 3) atomicAdd(&A.status->visits[33 + simd], 1ull);  // executor waves per SIMD (the rest sit on SIMD 3)
+        if (!claim_exec_s) atomicAdd(&A.status->visits[29], 1ull);     // executor waves that found no free SIMD
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

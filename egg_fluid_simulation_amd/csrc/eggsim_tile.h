@@ -306,22 +306,25 @@ __device__ __forceinline__ void project_pair(SameBatch same_batch, bool slow, do
 // path from the unchanged inputs.  Same operations in the same order as project_pair: same bits.
 // Returns whether pa / pb changed (the caller stores them or not by choosing the ADDRESS: the select of the address
 // needs only `fast`, known halfway down the chain, so neither a data select nor a store branch sits behind the last add).
-template <class SameBatch>
-__device__ __forceinline__ bool project_pair_predicated(SameBatch same_batch, bool active, bool slow, double2 &pa, double2 &pb,
-                                                        double2 wra, double2 wrb, double2 cached, double overlap,
-                                                        double compliance, double eps) {
+// after_first_use(): called once the positions have been consumed for the first time (the executor issues the scalar
+// load of a later chunk's descriptor there: in front of that point it would be waited for together with the positions).
+// wa / wb: the inverse masses; divisor = (wa + wb) + compliance, cached = (its refined reciprocal, the minimum distance),
+// md2 = minimum distance squared: all computed by the caller off the chain.  fetch_wr(wra, wrb): the whole (inverse
+// mass, radius) records, asked for only by the rare pair that takes the reference path.
+template <class SameBatch, class Hook, class FetchWr>
+__device__ __forceinline__ bool project_pair_predicated(SameBatch same_batch, Hook after_first_use, FetchWr fetch_wr, bool active,
+                                                        bool slow, double2 &pa, double2 &pb, double wa, double wb, double divisor,
+                                                        double2 cached, double md2, double overlap, double compliance, double eps) {
     const double dx = pb.x - pa.x, dy = pb.y - pa.y;
+    after_first_use();
     const double d2 = dx * dx + dy * dy;
     const double min_distance = cached.y;
-    const double md2 = min_distance * min_distance;
     const bool in_range = active && (((int)(d2 <= md2) | (int)slow) != 0);
     double current, r_current;
     egg_sqrt_rcp_core(d2, current, r_current);
     const double violation = current - min_distance;
     const bool fast = ((int)!slow & (int)(current >= eps) & (int)(fabs(dx) >= EGG_ARITH_LO) & (int)(fabs(dy) >= EGG_ARITH_LO) &
                        (int)(fabs(violation) >= EGG_ARITH_LO)) != 0;
-    const double wa = wra.x, wb = wrb.x;
-    const double divisor = (wa + wb) + compliance;
     const double nx = egg_div_with_rcp(dx, current, r_current);
     const double ny = egg_div_with_rcp(dy, current, r_current);
     double correction = egg_div_with_rcp(-violation, divisor, cached.x);
@@ -334,7 +337,8 @@ __device__ __forceinline__ bool project_pair_predicated(SameBatch same_batch, bo
     pa = make_double2(ax, ay);
     pb = make_double2(bx, by);
     if (__builtin_expect(in_range && !fast, 0)) {  // (the common case falls through one untaken branch)
-        double2 qa = pa0, qb = pb0;
+        double2 qa = pa0, qb = pb0, wra, wrb;
+        fetch_wr(wra, wrb);
         project_pair_reference(same_batch, qa, qb, wra, wrb, overlap, compliance, eps);
         pa = qa;
         pb = qb;

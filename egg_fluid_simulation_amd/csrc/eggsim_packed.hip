@@ -758,7 +758,7 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
     unsigned int turns = 0;
     bool over = false;
     const int sl = lane & 15, row = lane >> 4;
-    const int wpt = min((A.tune & 16) ? 1 : (A.tune & 32) ? 4 : 2, max(1, nwaves / nt)), conc = min(nt, nwaves);  // waves per tile (more than two only slow each other's polls down), tiles walked side by side
+    const int wpt = min(2, max(1, nwaves / nt)), conc = min(nt, nwaves);  // waves per tile (one: no overlap; four slow each other's polls down -- both measured), tiles walked side by side
     const int sub = wave / conc;
     for (int t = wave % conc; t < nt && sub < wpt; t += conc) {
         const int base = tile_base[t], slen = tile_len[t];
@@ -794,6 +794,9 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
             const uint32_t heads = (uint32_t)(__ballot(head) >> (row * 16)) & 0xFFFFu;
             const uint32_t upto = heads & (0xFFFFu >> (15 - sl));  // heads at lanes <= sl
             const int seg_start = 31 - __builtin_clz(upto | 1u);
+            // (later pieces of the row get a larger offset: an UNsegmented prefix maximum of value + offset then never
+            // takes its result from an earlier piece, and the scan needs no per-step segment test)
+            const int seg_off = __builtin_popcount(upto) << 20;
             const uint32_t above = heads >> (sl + 1);
             const uint32_t seg_end = above ? (uint32_t)(sl + 1 + __builtin_ctz(above)) : 16u;
             const uint32_t segmask = valid ? (0xFFFFu >> (16u - seg_end)) & ~((1u << seg_start) - 1u) : 0u;
@@ -827,24 +830,15 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
                 if (!__any(fire)) ++idle_turns;
 #endif
                 if (!__any(fire)) {
-                    if (A.tune == 1) __builtin_amdgcn_s_sleep(2);
-                    else if (A.tune == 2) __builtin_amdgcn_s_sleep(4);
-                    else if (A.tune == 3) __builtin_amdgcn_s_sleep(8);
-                    else if (A.tune != 4) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(1);  // (2, 4 and 8 were slower, none at all too: the polls of four waves crowd the LDS)
                     continue;
                 }
-                int v = fire ? (int)(wb & 0xFFFFu) - (int)pos : EGG_NEG_LEVEL;
-                {
-                    int tt;
-                    tt = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-                    if (fire && pos >= 1u) v = max(v, tt);
-                    tt = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-                    if (fire && pos >= 2u) v = max(v, tt);
-                    tt = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x114, 0xf, 0xf, false);  // row_shr:4
-                    if (fire && pos >= 4u) v = max(v, tt);
-                    tt = __builtin_amdgcn_update_dpp(EGG_NEG_LEVEL, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-                    if (fire && pos >= 8u) v = max(v, tt);
-                }
+                int v = fire ? (int)(wb & 0xFFFFu) - (int)pos + seg_off : EGG_NEG_LEVEL;
+                v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));  // row_shr:1 (lanes without a source keep their own)
+                v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+                v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+                v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+                v -= seg_off;
                 if (fire) {
                     const int lraw = (int)pos + 1 + max((int)(wa & 0xFFFFu), v);
                     maxlev = max(maxlev, lraw);  // deeper than the level table: reported below, the tables stay in range

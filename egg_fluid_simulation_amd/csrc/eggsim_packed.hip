@@ -809,7 +809,9 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
 #ifdef EGG_PROFILE
             acc_pro += __builtin_amdgcn_s_memtime() - p1;
 #endif
-            while (__any(valid && (uint32_t)sl >= f && f < seg_end)) {
+            const uint32_t seg_end_v = valid ? seg_end : 0u;  // (no pending lanes where there is no entry)
+            // (ballot != 0 instead of __any: the latter materialises the lane condition as 0 / 1 and compares again)
+            while (__builtin_amdgcn_ballot_w64((uint32_t)sl >= f && f < seg_end_v) != 0ull) {
                 ++turns;
 #ifdef EGG_PROFILE
                 const unsigned long long q0 = __builtin_amdgcn_s_memtime();
@@ -829,15 +831,20 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
 #ifdef EGG_PROFILE
                 if (!__any(fire)) ++idle_turns;
 #endif
-                if (!__any(fire)) {
+                if (__builtin_amdgcn_ballot_w64(fire) == 0ull) {
                     __builtin_amdgcn_s_sleep(1);  // (2, 4 and 8 were slower, none at all too: the polls of four waves crowd the LDS)
                     continue;
                 }
                 int v = fire ? (int)(wb & 0xFFFFu) - (int)pos + seg_off : EGG_NEG_LEVEL;
-                v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));  // row_shr:1 (lanes without a source keep their own)
-                v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));  // row_shr:2
-                v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));  // row_shr:4
-                v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+                // (one instruction per step -- lanes without a source keep their own value; written by hand because the
+                // compiler spells max(v, dpp(v)) as copy + move-with-DPP + max.  s_nop 1: a VGPR written by a VALU
+                // instruction may be read through DPP two wait states later)
+                __asm__ volatile(
+                    "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                    "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+                    "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+                    "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+                    : "+v"(v));
                 v -= seg_off;
                 if (fire) {
                     const int lraw = (int)pos + 1 + max((int)(wa & 0xFFFFu), v);

@@ -88,24 +88,56 @@ __device__ inline int pk_visit_fresh(const Tile &t, int gh, int cur, int i, F em
     return count;
 }
 
+// Packed cell keys are (x << 16 | y), both fields < 2^15.  With kbm = kb - 0x00010001 the difference t = ka - kbm holds
+// (dx + 1, dy + 1) in its two halves, so: ka lies in the 3x3 cells around kb <=> both halves are 0, 1 or 2, and then t
+// ORDERS the nine cells like the reference's loop (x offset outer, y inner, L:1568-1569): slot(ka) < slot(kc) <=>
+// t(ka) < t(kc).  (A borrow out of the low half leaves 0xFFFF.. there, which fails the test as it should.)
+__device__ __forceinline__ bool pk_adjacent(uint32_t t) { return ((t | (t + 0x00010001u)) & 0xFFFCFFFCu) == 0u; }
+
+// The stale pass (Q3: first pass of a later sub-step; the cell lists still hold the previous pass's entries in front of
+// this pass's, and `collided` still holds the previous pass's pairs).  The rules of accept_stale (eggsim_tile.h), taken
+// apart by what an entry's origin already decides -- the previous pass was not cut by the budget here (prev_uncut), so
+// "in collided" == "the two OLD cells are adjacent":
+//   * an OLD entry of cell c (j's old cell is c): the pair was visited before iff c is adjacent to i's old cell -- one
+//     test per CELL, and a self that kept its cell skips all nine old lists.  Otherwise j counts unless its new cell comes
+//     earlier in i's loop (first occurrence wins), or j < i and j's own loop met i (through i's new or old cell);
+//   * a NEW entry of cell c (j's new cell is c, adjacent to i's): j < i met i in its own loop, so only j > i counts,
+//     unless j's old cell comes earlier in i's loop or in the same cell (old entries stand in front), or the old cells
+//     are adjacent (visited before).
 template <class F>
 __device__ inline int pk_visit_stale(const Tile &t, int gh, const PassCtx &c, int i, F emit) {
     const uint32_t *kn = t.ckey(c.cur), *ko = t.ckey(c.prev);
     const uint32_t kni = kn[i], koi = ko[i];
-    const bool settled = c.prev_uncut && kni == koi;
+    const uint32_t knim = kni - 0x00010001u, koim = koi - 0x00010001u;
+    const uint16_t *items_o = t.hitems(c.prev), *items_n = t.hitems(c.cur);
     int count = 0;
     for (int s = 0; s < 9; ++s) {
-        const uint32_t nk = (uint32_t)((int)kni + (s / 3 - 1) * 65536 + (s % 3 - 1));
-        const uint32_t mo = pk_cell_meta(t, gh, c.prev, nk), mn = pk_cell_meta(t, gh, c.cur, nk);
-#pragma unroll
-        for (int isnew = 0; isnew < 2; ++isnew) {
-            const uint32_t m = isnew ? mn : mo;
-            const uint16_t *items = t.hitems(isnew ? c.cur : c.prev);
-            const int st = (int)(m >> 16), cn = (int)(m & 0xFFFFu);
+        const uint32_t ts = (uint32_t)(s / 3) << 16 | (uint32_t)(s % 3);  // this cell's place in the loop, as a key difference
+        const uint32_t nk = knim + ts;                                    // = kni + (s / 3 - 1, s % 3 - 1)
+        const uint32_t mn = pk_cell_meta(t, gh, c.cur, nk);
+        if (!pk_adjacent(nk - koim)) {  // (else every old entry of the cell was i's partner in the previous pass)
+            const uint32_t mo = pk_cell_meta(t, gh, c.prev, nk);
+            const int st = (int)(mo >> 16), cn = (int)(mo & 0xFFFFu);
             for (int e = 0; e < cn; ++e) {
-                const int j = (int)items[st + e];
-                const uint32_t knj = kn[j], koj = ko[j];
-                if (!(settled && knj == koj) && accept_stale(t, c, i, j, s, isnew, kni, koi, knj, koj)) {
+                const int j = (int)items_o[st + e];
+                const uint32_t knj = kn[j];
+                const uint32_t tn = knj - knim;
+                const bool near_new = pk_adjacent(tn);
+                const bool earlier = near_new && tn < ts;
+                const bool met_by_j = j < i && (near_new || pk_adjacent(knj - koim));
+                if (!earlier && !met_by_j) {
+                    emit(count, j);
+                    ++count;
+                }
+            }
+        }
+        const int st = (int)(mn >> 16), cn = (int)(mn & 0xFFFFu);
+        for (int e = 0; e < cn; ++e) {
+            const int j = (int)items_n[st + e];
+            if (j > i) {
+                const uint32_t koj = ko[j];
+                const uint32_t to = koj - knim;
+                if (!(pk_adjacent(to) && to <= ts) && !pk_adjacent(koj - koim)) {
                     emit(count, j);
                     ++count;
                 }
@@ -909,20 +941,24 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
         const int slen = tile_len[t];
         const uint32_t *stream = A.lists + (size_t)(t0 + t) * A.scap;
         const uint16_t *lv = llv + (size_t)t * lcap_lds;
-        for (int e0 = 0; e0 < slen; e0 += 12 * nthreads) {  // (twelve entries per lane requested before the first is used)
-            uint32_t rec[12], l[12];
+        // (32 entries per lane requested before the first is used: a dense tile's stream in one or two memory round trips
+        // instead of five)
+        for (int e0 = 0; e0 < slen; e0 += 32 * nthreads) {
+            uint32_t rec[32];
 #pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                const int e = min(e0 + u * nthreads + tid, slen - 1);
-                rec[u] = stream[e];
-                l[u] = (uint32_t)lv[e];
+            for (int u = 0; u < 32; ++u) rec[u] = stream[min(e0 + u * nthreads + tid, slen - 1)];
+            uint32_t pos[32];  // (every cursor is asked for before the first one is used; lanes beyond the stream add 0)
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int e = e0 + u * nthreads + tid;
+                const bool valid = e < slen;
+                const uint32_t l = (uint32_t)lv[min(e, slen - 1)];
+                pos[u] = __hip_atomic_fetch_add(&hist[l], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
 #pragma unroll
-            for (int u = 0; u < 12; ++u)
-                if (e0 + u * nthreads + tid < slen) {
-                    const uint32_t pos = atomicAdd(&hist[l[u]], 1u);
-                    sorted[pos] = 0x80000000u | ((rec[u] & 0x7FFFu) + base) | (rec[u] & 0x8000u) | ((((rec[u] >> 16) & 0x7FFFu) + base) << 16);
-                }
+            for (int u = 0; u < 32; ++u)
+                if (e0 + u * nthreads + tid < slen)
+                    sorted[pos[u]] = 0x80000000u | ((rec[u] & 0x7FFFu) + base) | (rec[u] & 0x8000u) | ((((rec[u] >> 16) & 0x7FFFu) + base) << 16);
         }
     }
 #ifdef EGG_PROFILE

@@ -210,7 +210,7 @@ static inline size_t egg_pk_levels_mr_lds_bytes(int lev_cap, int group_particles
 // ranking pass's entry counter per particle of the group
 // (+ a spare counter per lane), the levels of every stream entry of the group's tiles
 static inline size_t egg_pk_levels_ooo_lds_bytes(int lev_cap, int group_particles, int tiles, int lev_lds_cap) {
-    return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 4) + egg_align16((size_t)(group_particles + 64) * 4) +
+    return egg_align16((size_t)(lev_cap + 2) * 4) + egg_align16((size_t)group_particles * 4) + 2 * egg_align16((size_t)(group_particles + 64) * 4) +
            egg_align16((size_t)tiles * (size_t)lev_lds_cap * 2);
 }
 

@@ -712,18 +712,25 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
     q8 += egg_align16((size_t)np * 4);
     uint32_t *cnt = (uint32_t *)q8;   // [np + 64] entries seen so far per particle (the ranking pass)
     q8 += egg_align16((size_t)(np + 64) * 4);
+    uint32_t *cnt2 = (uint32_t *)q8;  // [np + 64] the same for the second half of a stream, when two waves rank a tile
+    q8 += egg_align16((size_t)(np + 64) * 4);
     // [nt][lev_lds_cap] the level of every stream entry.  In LDS because a level stored to global memory inside the walk
     // would make every wait for the next batch's entries a wait for those stores as well (loads and stores share one
     // counter, and the number of stores in between is not known at compile time): ~1,500 cycles per batch.
     uint16_t *llv = (uint16_t *)q8;
     const int lcap_lds = A.lev_lds_cap;
-    __shared__ int tile_base[64], tile_len[64];
+    __shared__ int tile_base[64], tile_len[64], tile_half[64];
     __shared__ int wave_max[16], wave_over[16];
     for (int i = tid; i <= lev_cap + 1; i += nthreads) hist[i] = 0;
     for (int i = tid; i < np + 64; i += nthreads) {  // (64 spare counters behind the particles: see the ranking pass)
         if (i < np) word[i] = 0;
         cnt[i] = 0;
+        cnt2[i] = 0;
     }
+    // With two waves to a tile the ranking is split: one wave counts the first half of the stream, the other the second
+    // half from zero in counters of its own; the second half's numbers lack the first half's totals per particle, which
+    // are simply what `cnt` holds when the pass is over -- the walk adds them when it sets a batch up.
+    const bool split_rank = 2 * nt <= nwaves;
     if (tid < nt) {  // the group's tiles: first particle (group-local), stream length
         tile_base[tid] = ((const int4 *)A.tile_geo)[2 * (t0 + tid)].x - p0;
         int slen = A.tile_total[t0 + tid];
@@ -732,21 +739,25 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
             slen = 0;
         }
         tile_len[tid] = slen;
+        tile_half[tid] = split_rank ? min(slen, ((slen >> 1) + 255) & ~255) : slen;  // (whole groups of four batches)
     }
     __syncthreads();
     EGG_STAMP(T0);
     // ---- ranking: one wave per tile, stream order.  expect(self) | expect(partner) << 16 per entry, into A.rank.
     // Every lane takes part in all three adds (a branch around an atomic costs a wait for its result): a lane whose
     // add does not apply adds 0 to a spare counter of its own.
-    for (int t = wave; t < nt; t += nwaves) {
+    for (int job = wave; job < (split_rank ? 2 * nt : nt); job += nwaves) {
+        const int t = split_rank ? job % nt : job, second = split_rank ? job / nt : 0;
         const int base = tile_base[t], slen = tile_len[t];
+        const int ebeg = second ? tile_half[t] : 0, eend = second ? slen : tile_half[t];
+        uint32_t *const cn = second ? cnt2 : cnt;
         const uint32_t *stream = A.lists + (size_t)(t0 + t) * A.scap;
         uint32_t *rank = A.rank + (size_t)(t0 + t) * A.scap;
         const int spare = np + lane;
         uint32_t nxt[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) nxt[u] = stream[min(64 * u + lane, max(slen - 1, 0))];
-        for (int e0 = 0; e0 < slen; e0 += 256) {
+        for (int u = 0; u < 4; ++u) nxt[u] = stream[min(ebeg + 64 * u + lane, max(slen - 1, 0))];
+        for (int e0 = ebeg; e0 < eend; e0 += 256) {
             uint32_t rec[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) rec[u] = nxt[u];
@@ -755,16 +766,16 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
             uint32_t xs[4], xo[4];  // (all adds go out before the first result is waited for)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool valid = e0 + 64 * u + lane < slen;
+                const bool valid = e0 + 64 * u + lane < eend;
                 const int a = (int)(rec[u] & 0x7FFFu), b = (int)((rec[u] >> 16) & 0x7FFFu);
                 const bool up = valid && b > a, down = valid && b < a;
-                xo[u] = __hip_atomic_fetch_add(&cnt[up ? base + b : spare], up ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                xo[u] = __hip_atomic_fetch_add(&cn[up ? base + b : spare], up ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __asm__ volatile("" ::: "memory");
                 // (the lanes of a run hit one address and are served in lane order: consecutive numbers)
-                xs[u] = __hip_atomic_fetch_add(&cnt[valid ? base + a : spare], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                xs[u] = __hip_atomic_fetch_add(&cn[valid ? base + a : spare], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __asm__ volatile("" ::: "memory");
                 if (__any(down)) {  // stale passes only
-                    const uint32_t x3 = __hip_atomic_fetch_add(&cnt[down ? base + b : spare], down ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t x3 = __hip_atomic_fetch_add(&cn[down ? base + b : spare], down ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __asm__ volatile("" ::: "memory");
                     xo[u] = up ? xo[u] : x3;
                 }
@@ -772,7 +783,7 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + 64 * u + lane;
-                if (e < slen) rank[e] = (xs[u] & 0xFFFFu) | (xo[u] << 16);
+                if (e < eend) rank[e] = (xs[u] & 0xFFFFu) | (xo[u] << 16);
             }
         }
     }
@@ -797,6 +808,7 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
         const uint32_t *stream = A.lists + (size_t)(t0 + t) * A.scap;
         const uint32_t *rank = A.rank + (size_t)(t0 + t) * A.scap;
         uint16_t *lv = llv + (size_t)t * lcap_lds;
+        const int half = tile_half[t];
         const int nb = (slen + 63) >> 6;
         // The entries (and their ranks) of a batch are requested TWO batches of this wave ahead of their use (a batch is
         // walked in ~1,500 cycles, less than a trip to memory): two register sets, the loop handles two batches per turn.
@@ -819,7 +831,11 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
             const int e = q * 64 + lane;
             const bool valid = e < slen;
             const int a = base + (int)(rec & 0x7FFFu), b = base + (int)((rec >> 16) & 0x7FFFu);
-            const uint32_t ea = rk & 0xFFFFu, eb = rk >> 16;
+            uint32_t ea = rk & 0xFFFFu, eb = rk >> 16;
+            if (q * 64 >= half) {  // (ranked from zero by the second wave: add what the first half of the stream held)
+                ea += cnt[a];
+                eb += cnt[b];
+            }
             // run pieces inside the row of 16 lanes
             const int a_prev = __builtin_amdgcn_update_dpp(-1, a, 0x111, 0xf, 0xf, false);  // row_shr:1
             const bool head = valid && (sl == 0 || a != a_prev);

@@ -181,17 +181,18 @@ struct EggPackedArgs {
 #define EGG_PK_WINDOW 128  // stream words a sub-wave of egg_pk_levels holds in LDS at a time
 
 // dynamic LDS of egg_pk_lists for the geometry above (must match eggsim_packed.hip)
-static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int use_grid, int stage_cap) {
-    size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, b = 0;
-    b += egg_align16(2 * n * 4);                  // ckey[2]
-    b += egg_align16(2 * c * 4);                  // cell[2]
-    b += egg_align16(use_grid ? 0 : 2 * c * 4);   // hkeys[2]
+// (gens: cell generations the launch holds -- 1 for a fresh pass, 2 for the stale pass)
+static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int use_grid, int stage_cap, int gens) {
+    size_t n = (size_t)nmax, a = (size_t)amax, c = (size_t)ccap, b = 0, G = (size_t)gens;
+    b += egg_align16(G * n * 4);                  // ckey[gens]
+    b += egg_align16(G * c * 4);                  // cell[gens]
+    b += egg_align16(use_grid ? 0 : G * c * 4);   // hkeys[gens]
     b += egg_align16((n + 1) * 4);                // own_off
     b += 2 * egg_align16(n * 4);                  // fill tmp
     b += egg_align16(a * 4 * 4);                  // aclaim
     b += egg_align16((a + 1) * 4);                // aoff
     b += egg_align16(16 * 4);                     // scalars
-    b += egg_align16(2 * n * 2);                  // hitems[2]
+    b += egg_align16(G * n * 2);                  // hitems[gens]
     b += 2 * egg_align16(n * 2);                  // pslot aslot
     b += egg_align16((size_t)stage_cap * n * 2);  // partners kept by the counting pass
     return b;

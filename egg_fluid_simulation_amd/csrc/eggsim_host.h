@@ -188,8 +188,8 @@ struct PackedClass {
     size_t chunk_base = 0;
     size_t lds_sort = 0;     // 0: the sort kernel scatters straight into global memory
     size_t entry_base = 0;  // first stream word of the class in the per-entry arrays
-    size_t lds_lists = 0, lds_levels = 0, lds_exec = 0;
-    int threads_lists = 64;
+    size_t lds_lists = 0, lds_lists_stale = 0, lds_levels = 0, lds_exec = 0;
+    int threads_lists = 64, threads_lists_stale = 64;
 };
 
 struct System {  // one particle type

@@ -426,18 +426,38 @@ int retile(egg_handle *h, int which) {
             pc.n_tiles = lc.n_tiles;
             pc.lcap = lc.lcap;
             pc.scap = lc.lcap;
-            pc.threads_lists = egg_step_threads(lc.nmax, 1);  // (capping it at 512 to fit a fourth dense tile per CU cost 50 %)
+            pc.threads_lists = pc.threads_lists_stale = egg_step_threads(lc.nmax, 1);
             // the counting pass keeps up to stage_cap partners per particle in LDS as long as that does not cost a
-            // resident tile per CU (residency: LDS and the 32-wave limit)
-            auto tiles_per_cu = [&](int stage) {
-                const size_t lds = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, stage);
+            // resident tile per CU (residency: LDS and the 32-wave limit); sized by the stale pass, which holds two cell generations
+            auto tiles_per_cu = [&](int stage, int gens, int threads) {
+                const size_t lds = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, stage, gens);
                 if (lds > h->lds_limit) return (size_t)0;  // (what a workgroup may have is a little less than the CU's 160 KiB)
-                return std::min<size_t>(kLdsMax / std::max<size_t>(lds, 1), (size_t)2048 / (size_t)pc.threads_lists);
+                return std::min<size_t>(kLdsMax / std::max<size_t>(lds, 1), (size_t)2048 / (size_t)threads);
             };
             for (pc.stage_cap = 16; pc.stage_cap > 0; pc.stage_cap -= 2)
-                if (tiles_per_cu(pc.stage_cap) == tiles_per_cu(0)) break;
-            pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap);
-            if (pc.lds_lists > h->lds_limit) continue;
+                if (tiles_per_cu(pc.stage_cap, 2, pc.threads_lists) == tiles_per_cu(0, 2, pc.threads_lists)) break;
+            pc.lds_lists = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap, 1);
+            pc.lds_lists_stale = egg_pk_lists_lds_bytes(lc.nmax, lc.amax, lc.ccap, lc.use_grid, pc.stage_cap, 2);
+            if (pc.lds_lists_stale > h->lds_limit) continue;
+            // Fewer threads than particles when that saves a whole round of workgroups: 1,024 dense tiles of 628 particles at
+            // 640 threads are three to a CU (32 waves), i.e. two rounds on 256 CUs; at 512 threads four fit -- if the LDS
+            // allows -- and one round of workgroups 1.5 x as long wins.  (Cost model: rounds x (1 + particles per thread) / 2.)
+            for (int kind = 0; kind < 2; ++kind) {
+                const int full = egg_step_threads(lc.nmax, 1);
+                int best = full;
+                double best_cost = 1e30;
+                for (int threads = full; threads >= 256; threads -= 64) {
+                    const size_t per_cu = tiles_per_cu(pc.stage_cap, kind + 1, threads);
+                    if (!per_cu) break;
+                    const double rounds = std::ceil((double)lc.n_tiles / ((double)per_cu * (double)std::max(1, h->prop.multiProcessorCount)));
+                    const double cost = rounds * 0.5 * (1.0 + std::ceil((double)lc.nmax / threads));
+                    if (cost < best_cost - 1e-9) {
+                        best_cost = cost;
+                        best = threads;
+                    }
+                }
+                (kind ? pc.threads_lists_stale : pc.threads_lists) = best;
+            }
             const size_t meta_mark = s.pk_meta_host.size();
             pc.p_begin = s.pk_n;
             pc.entry_base = s.pk_entries;

@@ -292,16 +292,17 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const 
         unsigned char *p = smem;
         t.pos = nullptr;  // (positions are only needed for the cells: each thread keeps its first particle's in registers)
         t.wr = nullptr;  // (inverse mass, radius) stay in global memory: only the rare slow-pair test reads them per pair
-        t.ckey_b = (uint32_t *)carve(p, 2 * n * 4);
-        t.cell_b = (uint32_t *)carve(p, 2 * cc * 4);
-        t.hkeys_b = (uint32_t *)carve(p, A.use_grid ? 0 : 2 * cc * 4);
+        constexpr size_t G = STALE ? 2 : 1;  // (a fresh pass holds one generation of cells: 6-7 KB less for a dense tile, a fourth tile per CU)
+        t.ckey_b = (uint32_t *)carve(p, G * n * 4);
+        t.cell_b = (uint32_t *)carve(p, G * cc * 4);
+        t.hkeys_b = (uint32_t *)carve(p, A.use_grid ? 0 : G * cc * 4);
         own_off = (uint32_t *)carve(p, (n + 1) * 4);
         t.fill = (uint32_t *)carve(p, n * 4);
         tmp = (uint32_t *)carve(p, n * 4);
         t.aclaim = (int32_t *)carve(p, a * 4 * 4);
         t.aoff = (int32_t *)carve(p, (a + 1) * 4);
         t.sc = (int32_t *)carve(p, 16 * 4);
-        t.hitems_b = (uint16_t *)carve(p, 2 * n * 2);
+        t.hitems_b = (uint16_t *)carve(p, G * n * 2);
         t.pslot = (uint16_t *)carve(p, n * 2);
         t.aslot = (uint16_t *)carve(p, n * 2);
         stage = A.stage_cap > 0 ? (uint16_t *)carve(p, (size_t)A.stage_cap * n * 2) : nullptr;
@@ -425,6 +426,14 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const 
         const int SC = A.stage_cap;
         for (int i = tid; i < n; i += nthreads) {
             const int cnt = (int)t.fill[i];
+#ifdef EGG_PROFILE
+            if (!STALE && tile < 64) {
+                if (cnt > SC) atomicAdd(&A.status->visits[16], 1ull);
+                if (__builtin_amdgcn_ballot_w64(cnt > SC) != 0ull && (tid & 63) == 0) atomicAdd(&A.status->visits[17], 1ull);
+                if ((tid & 63) == 0) atomicAdd(&A.status->visits[18], 1ull);
+                atomicMax(&A.status->visits[19], (unsigned long long)cnt);
+            }
+#endif
             uint32_t *dst = gstream + own_off[i];
             const double2 wi = all_fast ? make_double2(0.0, 0.0) : ((const double2 *)A.pk_wr)[p0 + i];
             auto emit = [&](int k, int j) {

@@ -269,7 +269,8 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
             }
             launch_some(0, stale ? EGG_PK_KIND_LISTS_STALE : EGG_PK_KIND_LISTS_FRESH,
                         [&](const PackedClass &) { return stale ? egg_pk_lists_stale_kernel : egg_pk_lists_fresh_kernel; }, tiles_of,
-                        [](const PackedClass &pc) { return pc.threads_lists; }, [](const PackedClass &pc) { return pc.lds_lists; });
+                        [stale](const PackedClass &pc) { return stale ? pc.threads_lists_stale : pc.threads_lists; },
+                        [stale](const PackedClass &pc) { return stale ? pc.lds_lists_stale : pc.lds_lists; });
             launch_some(1, EGG_PK_KIND_LEVELS, [](const PackedClass &pc) { return pc.levels_ooo ? egg_pk_levels_ooo_kernel : egg_pk_levels_mr16_kernel; },
                         groups_of, [](const PackedClass &pc) { return pc.levels_threads; }, [](const PackedClass &pc) { return pc.lds_levels; });
             {   // (the out-of-order walk sorts inside its own launch)

@@ -398,11 +398,18 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const 
         ctx.cut_mask = 0;
 
         // ---------------------------------------- visit lists: count (keeping what is found), offsets
+        // What the counting pass finds is kept, so that the lists are enumerated once.  A particle visits only partners with
+        // a larger index, so particle i has ~all its neighbours to keep and particle n - 1 - i ~none: the two SHARE 2 x
+        // stage_cap slots, i filling them from the front and its mirror image from the back (with stage_cap slots each,
+        // every fifth particle of a dense tile overflowed and 63 % of the waves had such a lane, which then enumerates again
+        // with the whole wave waiting).  Whether the two met in the middle is known when both are counted.
         const int SC = A.stage_cap;
         for (int i = tid; i < n; i += nthreads) {
-            uint16_t *slots = stage + (size_t)i * SC;
+            const int m = n - 1 - i, pair = min(i, m);
+            uint16_t *slots = stage + (size_t)pair * 2 * SC;
+            const int cap = m == i ? SC : 2 * SC, at = i <= m ? 0 : 2 * SC - 1, dir = i <= m ? 1 : -1;
             auto keep = [&](int k, int j) {
-                if (k < SC) slots[k] = (uint16_t)j;
+                if (k < cap) slots[at + dir * k] = (uint16_t)j;
             };
             t.fill[i] = STALE ? (uint32_t)pk_visit_stale(t, gh, ctx, i, keep) : (uint32_t)pk_visit_fresh(t, gh, cur, i, keep);
         }
@@ -428,8 +435,9 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const 
             const int cnt = (int)t.fill[i];
 #ifdef EGG_PROFILE
             if (!STALE && tile < 64) {
-                if (cnt > SC) atomicAdd(&A.status->visits[16], 1ull);
-                if (__builtin_amdgcn_ballot_w64(cnt > SC) != 0ull && (tid & 63) == 0) atomicAdd(&A.status->visits[17], 1ull);
+                const bool lost = (n - 1 - i == i) ? cnt > SC : cnt + (int)t.fill[n - 1 - i] > 2 * SC;
+                if (lost) atomicAdd(&A.status->visits[16], 1ull);
+                if (__builtin_amdgcn_ballot_w64(lost) != 0ull && (tid & 63) == 0) atomicAdd(&A.status->visits[17], 1ull);
                 if ((tid & 63) == 0) atomicAdd(&A.status->visits[18], 1ull);
                 atomicMax(&A.status->visits[19], (unsigned long long)cnt);
             }
@@ -447,12 +455,27 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const 
                 if (slow && wi.x + wj.x < A.eps) ++guarded;
                 dst[k] = (uint32_t)i | (slow ? 0x8000u : 0u) | ((uint32_t)j << 16);
             };
-            if (cnt <= SC && all_fast) {
-                const uint16_t *slots = stage + (size_t)i * SC;
-                for (int k = 0; k < cnt; ++k) dst[k] = (uint32_t)i | ((uint32_t)slots[k] << 16);
-            } else if (cnt <= SC) {
-                const uint16_t *slots = stage + (size_t)i * SC;
-                for (int k = 0; k < cnt; ++k) emit(k, (int)slots[k]);
+            const int m = n - 1 - i, pair = min(i, m);
+            const uint16_t *slots = stage + (size_t)pair * 2 * SC;
+            const int at = i <= m ? 0 : 2 * SC - 1, dir = i <= m ? 1 : -1;
+            const bool kept = m == i ? cnt <= SC : cnt + (int)t.fill[m] <= 2 * SC;  // (the two did not meet in the middle)
+            if (kept && all_fast) {
+                // (a scatter costs the compute unit's vector memory path about a cycle per LANE and store instruction, whatever
+                // its width: four entries per store, the address only dword-aligned -- which the compiler will not do)
+                int k = 0;
+                for (; k + 4 <= cnt; k += 4) {
+                    typedef uint32_t egg_u4 __attribute__((ext_vector_type(4)));
+                    egg_u4 v;
+                    v.x = (uint32_t)i | ((uint32_t)slots[at + dir * k] << 16);
+                    v.y = (uint32_t)i | ((uint32_t)slots[at + dir * (k + 1)] << 16);
+                    v.z = (uint32_t)i | ((uint32_t)slots[at + dir * (k + 2)] << 16);
+                    v.w = (uint32_t)i | ((uint32_t)slots[at + dir * (k + 3)] << 16);
+                    uint32_t *const where = dst + k;
+                    __asm__ volatile("global_store_dwordx4 %0, %1, off" : : "v"(where), "v"(v) : "memory");
+                }
+                for (; k < cnt; ++k) dst[k] = (uint32_t)i | ((uint32_t)slots[at + dir * k] << 16);
+            } else if (kept) {
+                for (int k = 0; k < cnt; ++k) emit(k, (int)slots[at + dir * k]);
             } else if (STALE) {
                 PassCtx ctx;
                 ctx.cur = cur;

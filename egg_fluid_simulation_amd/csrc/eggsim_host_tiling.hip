@@ -539,6 +539,18 @@ int retile(egg_handle *h, int which) {
                 const size_t guess = s.pk_seen_list ? (size_t)(s.pk_seen_list * 3 / 2 + 512) : (size_t)24 * lc.nmax;
                 pc.lev_lds_cap = (int)std::min<size_t>((size_t)pc.scap, std::max<size_t>(guess, s.pk_lev_lds_min));
                 pc.lev_lds_cap = (pc.lev_lds_cap + 7) & ~7;
+                // (more groups than CUs: two of them must fit a CU's LDS, or the launch takes two rounds.  The head room above
+                // must not cost that -- a dense island's first steps have streams twice as long as later ones, and half as
+                // much again on top of those is 98 KB per group)
+                if (pc.n_groups > std::max(1, h->prop.multiProcessorCount)) {
+                    const size_t budget = (kLdsMax - 4096) / 2;
+                    const size_t fixed = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles, max_tiles_in_group, 0);
+                    if (budget > fixed) {
+                        const size_t fit = ((budget - fixed) / ((size_t)max_tiles_in_group * 2)) & ~(size_t)7;
+                        const size_t need = std::max<size_t>((size_t)(s.pk_seen_list + s.pk_seen_list / 16 + 64), s.pk_lev_lds_min);
+                        if (fit >= need && (size_t)pc.lev_lds_cap > fit) pc.lev_lds_cap = (int)fit;
+                    }
+                }
                 pc.levels_threads = 64 * std::min(16, std::max((h->opt_tune & 8) ? 8 : 4, max_tiles_in_group));  // a wave per tile, at least four per group (eight were 10 % slower)
                 pc.lds_levels = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles, max_tiles_in_group, pc.lev_lds_cap);
                 if (pc.lds_levels > h->lds_limit) pc.levels_ooo = 0;  // (a stream too long for LDS: the in-order walk)

@@ -14,12 +14,12 @@ run() {  # name, counters
   cd /tmp && export TMPDIR=/tmp
   cd $root
   timeout -k 10 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $d -o p -- python3 bench.py "$@" --steps $steps --warmup $warm \
-      --no-cpu-baseline --no-latency --profile-steps 0 > $d/bench.json 2> $d/err.txt || echo "pass $1 FAILED rc=$?"
+      --no-cpu-baseline --no-latency --no-windows --profile-steps 0 > $d/bench.json 2> $d/err.txt || echo "pass $1 FAILED rc=$?"
 }
 args=("$@")
 pass() { name=$1; ctr=$2; d=$out/$name; mkdir -p $d; cd /tmp; export TMPDIR=/tmp; cd $root
   timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $d -o p -- python3 bench.py "${args[@]}" --steps $steps --warmup $warm \
-      --no-cpu-baseline --no-latency --profile-steps 0 > $d/bench.json 2> $d/err.txt || echo "pass $name FAILED rc=$?"; }
+      --no-cpu-baseline --no-latency --no-windows --profile-steps 0 > $d/bench.json 2> $d/err.txt || echo "pass $name FAILED rc=$?"; }
 pass fetch "FETCH_SIZE"
 pass write "WRITE_SIZE"
 pass sq_a "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"

@@ -59,12 +59,12 @@ if tot.get("SQ_ACTIVE_INST_VALU"):
     valu = {
         "valu_insts_per_step": tot["SQ_INSTS_VALU"] / steps,
         "lanes_per_inst": tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_ACTIVE_INST_VALU"] if tot.get("SQ_THREAD_CYCLES_VALU") else None,
-        # egg_pk_exec_chain_kernel keeps all 64 lanes enabled and selects afterwards (project_pair_predicated), so its lanes
+        # egg_pk_exec_chain_kernel (and the executor inside egg_pk_levexec_kernel) keeps all 64 lanes enabled and selects afterwards (project_pair_predicated), so its lanes
         # per instruction say nothing about useful lanes: the same ratio over every other kernel
         "lanes_useful": (lambda tc, ac: tc / ac if ac else None)(
-            sum(c.get("SQ_THREAD_CYCLES_VALU", 0.0) for k, c in per_kernel.items() if k.startswith("egg_") and "exec_chain" not in k),
-            sum(c.get("SQ_ACTIVE_INST_VALU", 0.0) for k, c in per_kernel.items() if k.startswith("egg_") and "exec_chain" not in k)),
-        "lanes_useful_note": "lanes per VALU instruction over all kernels except egg_pk_exec_chain_kernel (predicated: every lane enabled)",
+            sum(c.get("SQ_THREAD_CYCLES_VALU", 0.0) for k, c in per_kernel.items() if k.startswith("egg_") and "exec_chain" not in k and "levexec" not in k),
+            sum(c.get("SQ_ACTIVE_INST_VALU", 0.0) for k, c in per_kernel.items() if k.startswith("egg_") and "exec_chain" not in k and "levexec" not in k)),
+        "lanes_useful_note": "lanes per VALU instruction over all kernels except egg_pk_exec_chain_kernel and egg_pk_levexec_kernel (their executors are predicated: every lane enabled; the walk of the latter polls with all lanes)",
         "wave_time_valu_active": tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_WAVE_CYCLES"],
         "wave_time_any_inst_active": tot["SQ_ACTIVE_INST_ANY"] / tot["SQ_WAVE_CYCLES"],
         "wave_time_waiting": tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"],

@@ -675,6 +675,8 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
                 fprintf(stderr, "   group 0 wave 0: %llu turns; cycles waiting for the batch's entries %llu, in the batch set-up %llu, in the turns %llu\n", st.visits[38], st.visits[36], st.visits[39], st.visits[37]);
                 fprintf(stderr, "   executor of group 0: %llu cycles for %llu chunks = %.1f per chunk; slowest group %.1f per chunk\n", st.visits[30], st.visits[31],
                         (double)st.visits[30] / (double)std::max<unsigned long long>(st.visits[31], 1), (double)st.visits[32] / 16.0);
+                fprintf(stderr, "   executor of group 0: %llu ticks of the 100 MHz clock, i.e. the cycle counter ran at %.0f MHz\n", st.visits[28], st.visits[28] ? 100.0 * (double)st.visits[30] / (double)st.visits[28] : 0.0);
+                fprintf(stderr, "   executor of group 0 looked at the helper's progress %llu times and spent %llu cycles there\n", st.visits[26], st.visits[27]);
                 fprintf(stderr, "   executor waves on SIMD 0 / 1 / 2 (all passes of the step): %llu %llu %llu; without a SIMD of their own: %llu\n", st.visits[33], st.visits[34], st.visits[35], st.visits[29]);
                 fprintf(stderr, "   groups by total cycles (25k buckets):");
                 for (int k = 0; k < 15; ++k) fprintf(stderr, " %llu", st.visits[40 + k]);

@@ -1436,19 +1436,32 @@ __device__ __forceinline__ void egg_pk_exec_consumer(const EggPackedArgs &A, con
     egg_lds_v2d *const lp = (egg_lds_v2d *)smem;
     egg_lds_v2d *const spare = lp + np + lane;  // lanes with nothing to store write their own spare slot
     int seen = 0;  // chunks the helper is known to have finished
+#ifdef EGG_PROFILE
+    unsigned long long waited = 0, polls = 0;
+#endif
     auto wait_for = [&](int chunk) {
         if (__builtin_expect(seen <= chunk, 0)) {
+#ifdef EGG_PROFILE
+            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+            ++polls;
+#endif
             for (;;) {
                 seen = (int)__builtin_amdgcn_readfirstlane(*ring.produced);
                 if (seen > chunk) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+#ifdef EGG_PROFILE
+            waited += __builtin_amdgcn_s_memtime() - w0;
+#endif
         }
         __asm__ volatile("" ::: "memory");
     };
     wait_for(0);
     egg_v2d ra = ring.a[lane], rc = ring.c[lane], rd = ring.d[lane];
     egg_v2u rq = ring.q[lane];
+    // (the helper's progress is read with every chunk's records and looked at a chunk later, when it has long arrived: a
+    // look of its own is an LDS round trip on the executor's path -- 117 of them per 432 chunks, 8 % of its time)
+    uint32_t peek = 0;
     for (int c0 = 0; c0 < nch_pad; c0 += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1461,7 +1474,9 @@ __device__ __forceinline__ void egg_pk_exec_consumer(const EggPackedArgs &A, con
             egg_v2d ra1 = ra, rc1 = rc, rd1 = rd;
             egg_v2u rq1 = rq;
             if (u < 7 || c + 1 < nch_pad) {
+                seen = max(seen, (int)__builtin_amdgcn_readfirstlane(peek));
                 wait_for(c + 1);
+                peek = *ring.produced;
                 const int slot = ((u + 1) & (EGG_PK_RING - 1)) * 64 + lane;
                 ra1 = ring.a[slot];
                 rc1 = ring.c[slot];
@@ -1498,6 +1513,12 @@ __device__ __forceinline__ void egg_pk_exec_consumer(const EggPackedArgs &A, con
         }
     }
     for (int i = lane; i < np; i += 64) gpos[i] = lpos[i];
+#ifdef EGG_PROFILE
+    if (g == 0 && lane == 0) {
+        A.status->visits[27] = waited;
+        A.status->visits[26] = polls;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1572,6 +1593,9 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_levexec_kernel(EggPacke
     }
     if (wave != exec_wave_s) return;
     EGG_STAMP(E0);
+#ifdef EGG_PROFILE
+    const unsigned long long R0 = __builtin_amdgcn_s_memrealtime();
+#endif
     egg_pk_exec_consumer(A, g, ring);
     if ((threadIdx.x & 63) == 0 && claim_exec_s) atomicAnd(&A.simd_claims[claim_key_s], ~claim_exec_s);
 #ifdef EGG_PROFILE
@@ -1582,6 +1606,7 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_levexec_kernel(EggPacke
         if (g == 0) {
             A.status->visits[30] = E1 - E0;
             A.status->visits[31] = nch;
+            A.status->visits[28] = __builtin_amdgcn_s_memrealtime() - R0;  // 100 MHz ticks of the same interval
         }
         atomicMax(&A.status->visits[32], (E1 - E0) * 16ull / nch);  // slowest group, cycles per chunk x 16
         const uint32_t simd = (hw_id >> 4) & 3u;

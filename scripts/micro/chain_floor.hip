@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(64) chain3(int levels, const double2 *gwr, uns
     v2d A = ringA[lane], C = ringC[lane], D = ringD[lane];
     v2u Q = ringQ[lane];
     uint32_t seen = 0;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #define PIN(x) __asm__ volatile("" : "+v"(x))
     for (int l = 0; l < levels; l += 8) {
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(64) chain3(int levels, const double2 *gwr, uns
 #undef PIN
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (lane == 0) out[blockIdx.x] = t1 - t0;
+    if (lane == 0 && blockIdx.x == 0) printf("   (chain3: %llu cycle-counter ticks in %llu ticks of the 100 MHz clock: %.0f MHz)\n", t1 - t0, __builtin_amdgcn_s_memrealtime() - r0, 100.0 * (double)(t1 - t0) / (double)(__builtin_amdgcn_s_memrealtime() - r0));
     const v2d r = lpos[lane];
     sink[blockIdx.x * 64 + lane] = make_double2(r.x, r.y);
 }

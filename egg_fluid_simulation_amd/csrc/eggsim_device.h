@@ -172,7 +172,7 @@ struct EggPackedArgs {
     double sub_delta, damping, follow_compliance, collision_compliance, overlap_factor, cell_size, eps;
     int32_t n_substeps, n_collision_steps;
     int32_t pass_seq, substep, stale;  // of the launch
-    int32_t tune;              // developer experiments (EGGSIM_TUNE), 0 in normal operation
+    int32_t tune;              // developer switches (EGGSIM_TUNE), 0 in normal operation; unused by the kernels at present
     uint32_t *simd_claims;     // [4096] per compute unit: SIMDs taken by executor waves of egg_pk_levexec_kernel right now
     int32_t lev_lds_cap;       // out-of-order walk: entries of a tile's stream whose levels fit the LDS array of the launch
     EggStatus *status, *status_next;

@@ -303,7 +303,7 @@ struct egg_handle {
     int opt_spread = 0;  // threads per particle: 0 = automatic (3 for tiles that have a CU to themselves), else 1..4
     int opt_spin_sleep = -1;  // -1 auto
     bool packed_auto = false;  // the automatic choice, made when the white tiles are formed
-    int opt_tune = 0;         // EGGSIM_TUNE: developer experiments inside the packed kernels
+    int opt_tune = 0;         // EGGSIM_TUNE: developer switches (bit 6: levels, sort and executor as separate launches instead of the fused pass)
     int opt_level_walk = 0;   // packed pipeline, EGG_OPT_LEVEL_WALK: 0 by regime, 1 always in order, 2 out of order wherever the probe allows
     DevBuf<uint32_t> simd_claims;   // egg_pk_levexec_kernel: which SIMDs of a compute unit run an executor wave (zero between launches)
     bool lds_lane_ordered = false;  // one ds_add_rtn serves same-address lanes in ascending lane order (probed at create)

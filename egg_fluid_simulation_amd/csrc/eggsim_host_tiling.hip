@@ -551,7 +551,7 @@ int retile(egg_handle *h, int which) {
                         if (fit >= need && (size_t)pc.lev_lds_cap > fit) pc.lev_lds_cap = (int)fit;
                     }
                 }
-                pc.levels_threads = 64 * std::min(16, std::max((h->opt_tune & 8) ? 8 : 4, max_tiles_in_group));  // a wave per tile, at least four per group (eight were 10 % slower)
+                pc.levels_threads = 64 * std::min(16, std::max(4, max_tiles_in_group));  // a wave per tile, at least four per group (eight were 10 % slower)
                 pc.lds_levels = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles, max_tiles_in_group, pc.lev_lds_cap);
                 if (pc.lds_levels > h->lds_limit) pc.levels_ooo = 0;  // (a stream too long for LDS: the in-order walk)
             }

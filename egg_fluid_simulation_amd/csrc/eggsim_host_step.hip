@@ -290,7 +290,7 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
             launch_some(1, EGG_PK_KIND_EXEC, [&](const PackedClass &pc) { return pc.n_groups <= simds ? egg_pk_exec_chain_kernel : egg_pk_exec_kernel; }, groups_of, c64,
                         [&](const PackedClass &pc) { return pc.lds_exec + (pc.n_groups <= simds ? 64 * 16 : 0); });
             // dense islands on a chip that is not full: levels, sort and executor of a group in one launch
-            launch_some(2, EGG_PK_KIND_PASS, [](const PackedClass &) { return egg_pk_levexec_kernel; }, groups_of, c256,
+            launch_some(2, EGG_PK_KIND_PASS, [](const PackedClass &) { return egg_pk_levexec_kernel; }, groups_of, [](const PackedClass &pc) { return pc.levels_threads; },
                         [](const PackedClass &pc) { return pc.lds_pass; });
         }
     }
@@ -666,7 +666,11 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
             }
             h->stats.max_pass_visits[w] = most;
             h->stats.max_levels[w] = s.pk.empty() ? 0 : st.max_level;
-            if (!s.pk.empty()) s.pk_seen_list = st.max_list;
+            if (!s.pk.empty()) {
+                s.pk_seen_list = st.max_list;
+                s.pk_seen_levels = st.max_level;
+                if (s.pk_group4_applies && egg_wants_group4(s) != s.pk_group4) s.tiling_dirty = true;  // (the grouping follows the shape of the dependency graph)
+            }
 #ifdef EGG_PROFILE
             if (getenv("EGGSIM_DEBUG") && !s.pk.empty())
                 fprintf(stderr, "eggsim: type %d step %lld, last pass, egg_pk_levels_ooo cycles: group 0 init %llu rank %llu walk %llu finish %llu sort %llu total %llu | slowest group: walk %llu total %llu | turns %llu levels %d\n",

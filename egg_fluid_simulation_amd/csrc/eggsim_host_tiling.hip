@@ -3,6 +3,14 @@
 
 namespace egghost {
 
+// Dense islands, four to an executor instead of two?  When a pass has fewer than 5 pairs per level and island (back to two
+// from 7: the scene drifts slowly, and a change of grouping is a re-tiling).
+bool egg_wants_group4(const System &s) {
+    if (s.pk_seen_levels <= 0) return false;
+    const double pairs_per_level = (double)s.pk_seen_list / (double)s.pk_seen_levels;
+    return pairs_per_level < (s.pk_group4 ? 7.0 : 5.0);
+}
+
 
 // ------------------------------------------------------------------ tiling
 
@@ -398,6 +406,7 @@ int retile(egg_handle *h, int which) {
     // ---- packed pipeline (eggsim_packed.hip): which classes take it, their packed ranges and groups
     s.pk.clear();
     s.pk_meta_host.clear();
+    s.pk_group4_applies = false;
     s.pk_n = s.pk_tiles = s.pk_groups = 0;
     s.pk_entries = 0;
     s.pk_sort_words = 0;
@@ -503,6 +512,14 @@ int retile(egg_handle *h, int which) {
                 const int64_t simds = 4 * (int64_t)std::max(1, h->prop.multiProcessorCount);
                 gp_auto = std::min<int64_t>(1280, std::max<int64_t>(320, (class_particles / simds + 159) / 160 * 160));
             }
+            else if (lc.n_tiles > 2 * std::max(1, h->prop.multiProcessorCount) && (s.pk_group4_applies = true, s.pk_group4 = egg_wants_group4(s))) {
+                // Dense islands whose dependency graph has become deep and narrow (config 3 after some hundred steps: 6,500
+                // pairs in 1,900 levels, 3-4 pairs per level and island): four islands to a group -- still one chunk per
+                // level, half as many executor waves and ONE group per CU, whose executor then has the CU's LDS to itself
+                // (542 instead of 586 cycles per level; with wider levels the chunks would split: +37 % chunks at 10 pairs
+                // per level and island, which is why this is not the rule).
+                gp_auto = 2560;
+            }
             const int64_t gp_max = std::max<int64_t>(h->opt_group_particles > 0 ? h->opt_group_particles : gp_auto,
                                                      tiles[(size_t)lc.first_tile].particles);
             int max_tiles_in_group = 0;
@@ -551,12 +568,13 @@ int retile(egg_handle *h, int which) {
                         if (fit >= need && (size_t)pc.lev_lds_cap > fit) pc.lev_lds_cap = (int)fit;
                     }
                 }
-                pc.levels_threads = 64 * std::min(16, std::max(4, max_tiles_in_group));  // a wave per tile, at least four per group (eight were 10 % slower)
+                // a wave per tile, at least four per group (eight for two tiles were 10 % slower); two waves per tile for up to four
+                pc.levels_threads = 64 * std::min(16, std::max(4, max_tiles_in_group <= 4 ? 2 * max_tiles_in_group : max_tiles_in_group));
                 pc.lds_levels = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles, max_tiles_in_group, pc.lev_lds_cap);
                 if (pc.lds_levels > h->lds_limit) pc.levels_ooo = 0;  // (a stream too long for LDS: the in-order walk)
             }
             // (levels + sort + executor in one launch: whenever the out-of-order walk runs with four waves in the latency regime)
-            pc.fused_pass = pc.levels_ooo && pc.levels_threads == 256 && pc.n_groups <= simds && !(h->opt_tune & 64);
+            pc.fused_pass = pc.levels_ooo && pc.levels_threads <= 512 && max_tiles_in_group <= 4 && pc.n_groups <= simds && !(h->opt_tune & 64);
             if (!pc.levels_ooo) {
                 pc.levels_threads = std::min(256, (max_tiles_in_group * 16 + 63) / 64 * 64);
                 pc.lds_levels = egg_pk_levels_mr_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.levels_threads);

@@ -1529,18 +1529,18 @@ __device__ __forceinline__ void egg_pk_exec_consumer(const EggPackedArgs &A, con
 // (The list kernel stays a launch of its own: its 640-thread workgroups at 42 registers fit three per CU; with this
 // kernel's registers only two would, and the second half of the islands would wait for a whole pass of the first --
 // measured: 3.4 ms per step against 2.4.)
-extern "C" __global__ void __launch_bounds__(256) egg_pk_levexec_kernel(EggPackedArgs A) {
+extern "C" __global__ void __launch_bounds__(512) egg_pk_levexec_kernel(EggPackedArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int g = blockIdx.x;
     if (g >= A.n_groups) return;
-    pk_levels_ooo_body(A, g, 256);
+    pk_levels_ooo_body(A, g, (int)blockDim.x);  // four waves for up to two tiles, eight for up to four
     __threadfence_block();  // (the sorted list and the chunk descriptors just stored are read back below)
     // Which waves become the executor and its helper?  Two groups share a compute unit, each with a wave on every SIMD.
     // An executor wave is bound by its own instruction issue, so two of them on one SIMD run at half speed each -- with
     // "wave 0" for everybody that happened on a quarter of the compute units (780-830 cycles per level there against
     // 640).  So the executor and helper waves of a compute unit claim their SIMDs in a per-unit word in global memory:
     // a group takes SIMDs no other group's executor or helper is on, and gives them back when it is done.
-    __shared__ uint32_t simd_of_wave[4];
+    __shared__ uint32_t simd_of_wave[8];
     __shared__ int exec_wave_s, help_wave_s;
     __shared__ uint32_t claim_key_s, claim_exec_s, claim_help_s;
     __shared__ uint32_t ring_produced, ring_consumed;
@@ -1551,8 +1551,9 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_levexec_kernel(EggPacke
     if (threadIdx.x == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID: XCC_ID 3:0
         const uint32_t key = ((hw_id >> 8) & 0xFFu) | (xcc << 8);
+        const int nwaves = (int)(blockDim.x >> 6);
         uint32_t present = 0;
-        for (int w = 0; w < 4; ++w) present |= 1u << simd_of_wave[w];
+        for (int w = 0; w < nwaves; ++w) present |= 1u << simd_of_wave[w];
         uint32_t got[2] = {0, 0};
         uint32_t seen = __hip_atomic_load(&A.simd_claims[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int role = 0; role < 2; ++role)
@@ -1568,12 +1569,12 @@ extern "C" __global__ void __launch_bounds__(256) egg_pk_levexec_kernel(EggPacke
                 }
             }
         int ew = -1, hw = -1;
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < nwaves; ++w) {
             if (got[0] && ew < 0 && (1u << simd_of_wave[w]) == got[0]) ew = w;
             if (got[1] && hw < 0 && (1u << simd_of_wave[w]) == got[1]) hw = w;
         }
         if (ew < 0) ew = 0;
-        if (hw < 0 || hw == ew) hw = (ew + 1) & 3;
+        if (hw < 0 || hw == ew) hw = (ew + 1) % nwaves;
         exec_wave_s = ew;
         help_wave_s = hw;
         claim_key_s = key;

@@ -271,6 +271,31 @@ def test_packed_pipeline_dense_and_sparse_islands_with_hand_made_chaos(egg, orac
     assert h.stats()["packed"][WHITE] >= 1 and _walk_used(h, walk)
 
 
+def test_fused_pass_with_four_dense_islands_to_an_executor(egg, oracle_mod):
+    """Deep, narrow dependency graphs are grouped four dense islands to an executor (retile: egg_wants_group4): the fused
+    pass then runs eight waves per group (two walk a tile, one executes, one helps).  Forced here with
+    EGG_OPT_GROUP_PARTICLES on six sites of four coincident batches -- groups of four and of two islands -- with the first
+    steps' coincident particles (distance 0: the reference path inside the executor) and a moving target."""
+    from egg_fluid_simulation_amd import _ffi
+    h, o = _packed(egg, 2), oracle_mod.Oracle()
+    h.set_option(_ffi.OPT_GROUP_PARTICLES, 2560)
+    centers = [(300.0 + 260.0 * (k % 3), 300.0 + 260.0 * (k // 3)) for k in range(6) for _ in range(4)]
+    ids = []
+    for x, y in centers:
+        ids.append(h.add(x, y, 50, 15))
+        assert o.add(x, y, 50, 15) == ids[-1]
+    for step in range(12):
+        h.set_target_position(ids[0], 300.0 + 2.0 * step, 300.0)
+        o.set_target_position(ids[0], 300.0 + 2.0 * step, 300.0)
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+        if step % 3 == 2:
+            _same(h, o, step)
+    _same(h, o, "end")
+    st = h.stats()
+    assert st["pk_variants"][WHITE] & _ffi.PK_VARIANT_PASS_FUSED and st["max_tile_particles"][WHITE] == 4 * N_W
+
+
 @pytest.mark.parametrize("walk", WALKS)
 def test_packed_pipeline_inverse_masses_between_half_eps_and_eps(egg, oracle_mod, walk):
     """every inverse mass in [eps / 2, eps): the tile-wide 'all pairs take the fast path' test of the list kernel holds

@@ -90,11 +90,19 @@ def _check_budget_not_binding(st):
     assert st["single_tile"] == [0, 0]
 
 
-def test_config3_full_size_every_site_vs_oracle(egg, oracle_mod):
-    """4,096 batches, four coincident per site, the automatic path: the scene bench.py times"""
-    n, overlap, steps = 4096, 4, 3
+@pytest.mark.parametrize("islands_per_executor", [2, 4])
+def test_config3_full_size_every_site_vs_oracle(egg, oracle_mod, islands_per_executor):
+    """4,096 batches, four coincident per site, the automatic path: the scene bench.py times.  Four islands per executor
+    is the grouping the host switches to by itself once the dependency graphs are deep and narrow (hundreds of steps in);
+    forced here so that all 1,024 sites are compared on it as well."""
+    # (four islands per executor: 40 steps, by which the pair streams have shrunk far enough for four islands' level arrays
+    # to fit the LDS -- before that the host falls back to the in-order walk for such groups)
+    n, overlap, steps = 4096, 4, (3 if islands_per_executor == 2 else 40)
     xs, ys = _bench_layout(n, overlap)
     h = egg.SimulationHandler()
+    if islands_per_executor == 4:
+        from egg_fluid_simulation_amd import _ffi as ffi_
+        h.set_option(ffi_.OPT_GROUP_PARTICLES, 2560)
     ids = h.add_many(xs, ys, 50, 15)
     for _ in range(steps):
         assert h.update(1 / 60) == 1

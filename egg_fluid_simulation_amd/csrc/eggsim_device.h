@@ -199,6 +199,7 @@ static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int us
 }
 // egg_pk_levexec_kernel: the ring of ready-made pair records between its helper wave and its executor wave:
 // EGG_PK_RING chunks x 64 lanes x (8 B addresses + 3 x 16 B constants)
+#define EGG_PK_SPIN_LIMIT (1u << 24)  // polls a wave of the packed pipeline waits for another wave before it gives up (fail_stall = 4): seconds
 #define EGG_PK_RING 8
 #define EGG_PK_RING_BYTES (EGG_PK_RING * 64 * 56)
 // dynamic LDS of egg_pk_levels_mr16 (the in-order walk): level histogram, last level and a stamp word per particle of the

@@ -575,6 +575,12 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
                 h->stats.kernel_ms[w] = (double)t;
             }
             const EggStatus &st = *s.h_status;
+            if (st.fail_stall)
+                return fail(h, EGG_ERR_INTERNAL, "pair scheduler stalled (type %d, %s)", w,
+                            st.fail_stall == 2 ? "time limit reached"
+                            : st.fail_stall == 3 ? "workgroup narrower than the wide kernel needs"
+                            : st.fail_stall == 4 ? "a wait between the waves of the packed pipeline did not end"
+                                                 : "a particle's pair sequence did not finish");
             if (st.fail_overflow) {
                 // more visited pairs than the launch had list room for: grow and re-run
                 s.list_min = std::max<size_t>(s.list_min, (size_t)(st.max_list * 5 / 4 + 64));
@@ -627,11 +633,6 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
                 redo = true;
                 continue;
             }
-            if (st.fail_stall)
-                return fail(h, EGG_ERR_INTERNAL, "pair scheduler stalled (type %d, %s)", w,
-                            st.fail_stall == 2 ? "time limit reached"
-                            : st.fail_stall == 3 ? "workgroup narrower than the wide kernel needs"
-                                                 : "a particle's pair sequence did not finish");
             const bool single = s.single_tile || h->opt_force_single;
             if (!single) {
                 // budget check (L:1657-1658): the return can only fire if some pass visits more than

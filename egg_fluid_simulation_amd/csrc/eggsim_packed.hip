@@ -912,6 +912,7 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
                 if (!__any(fire)) ++idle_turns;
 #endif
                 if (__builtin_amdgcn_ballot_w64(fire) == 0ull) {
+                    if (turns >= EGG_PK_SPIN_LIMIT) break;  // (never in a consistent stream: give up -- reported below -- instead of hanging the GPU; looked at on idle turns only)
                     __builtin_amdgcn_s_sleep(1);  // (2, 4 and 8 were slower, none at all too: the polls of four waves crowd the LDS)
                     continue;
                 }
@@ -954,7 +955,8 @@ __device__ __forceinline__ void pk_levels_ooo_body(const EggPackedArgs &A, const
             }
         }
     }
-    over = maxlev > lev_cap;
+    over = maxlev > lev_cap || turns >= EGG_PK_SPIN_LIMIT;  // (a wave that gave up leaves levels undefined: nothing of this group is used)
+    if (turns >= EGG_PK_SPIN_LIMIT && lane == 0) atomicExch(&A.status->fail_stall, 4);
     EGG_STAMP(T3);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) maxlev = max(maxlev, __shfl_xor(maxlev, d, 64));
@@ -1375,6 +1377,7 @@ __device__ __forceinline__ void egg_pk_exec_helper(const EggPackedArgs &A, const
         wb[u] = gwr[(rec[u] >> 16) & 0x7FFFu];
     }
     int room = EGG_PK_RING;  // chunks below this index may be written: consumed + EGG_PK_RING
+    unsigned spins = 0;       // polls spent waiting for the executor, over the whole list (a guard against hanging the GPU)
     for (int k0 = 0; k0 < nch_pad; k0 += R) {
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -1399,8 +1402,8 @@ __device__ __forceinline__ void egg_pk_exec_helper(const EggPackedArgs &A, const
             if (k >= room) {  // the ring is full: wait for the executor
                 for (;;) {
                     room = (int)__builtin_amdgcn_readfirstlane(*ring.consumed) + EGG_PK_RING;
-                    if (k < room) break;
-                    __builtin_amdgcn_s_sleep(4);
+                    if (k < room || ++spins >= EGG_PK_SPIN_LIMIT) break;  // (the second: the executor is gone -- reported below)
+                    __builtin_amdgcn_s_sleep(1);  // (4, 16, 32 were slower: the executor runs dry when the helper reacts late)
                 }
             }
             const int slot = (u & (EGG_PK_RING - 1)) * 64 + lane;
@@ -1413,6 +1416,7 @@ __device__ __forceinline__ void egg_pk_exec_helper(const EggPackedArgs &A, const
             __asm__ volatile("" ::: "memory");
         }
     }
+    if (spins >= EGG_PK_SPIN_LIMIT && lane == 0) atomicExch(&A.status->fail_stall, 4);
 }
 
 __device__ __forceinline__ void egg_pk_exec_consumer(const EggPackedArgs &A, const int g, const PkRing ring) {
@@ -1445,9 +1449,14 @@ __device__ __forceinline__ void egg_pk_exec_consumer(const EggPackedArgs &A, con
             const unsigned long long w0 = __builtin_amdgcn_s_memtime();
             ++polls;
 #endif
-            for (;;) {
+            for (unsigned spins = 0;; ++spins) {
                 seen = (int)__builtin_amdgcn_readfirstlane(*ring.produced);
                 if (seen > chunk) break;
+                if (spins >= EGG_PK_SPIN_LIMIT) {  // (the helper is gone: give up loudly -- the step is an error then; the rest of
+                    if (lane == 0) atomicExch(&A.status->fail_stall, 4);  // the loop runs through on whatever the ring holds)
+                    seen = 0x7FFFFFFF;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
 #ifdef EGG_PROFILE

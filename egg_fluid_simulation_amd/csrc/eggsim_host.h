@@ -180,7 +180,10 @@ struct PackedClass {
     int max_group_particles = 0;
     int fused_pass = 0;     // 1: levels, sort and executor of a group are ONE launch (egg_pk_levexec_kernel)
     size_t lds_pass = 0;    // its dynamic LDS: the larger of the two phases
-    int lev_lds_cap = 0;    // out-of-order walk: stream entries per tile whose levels the LDS of the launch holds
+    int lev_lds_cap = 0;    // out-of-order walk: stream entries per tile whose levels the LDS of a launch may hold (sized at re-tiling)
+    int lev_lds_now = 0;    // ... and holds in this step's launches: no more than the last step's longest stream + 25 % asks for
+    size_t lds_levels_now = 0, lds_pass_now = 0;
+    int max_tiles_in_group = 0;
     int levels_ooo = 0;     // the level walk of the class: 0 in order (egg_pk_levels_mr16_kernel), 1 out of order (egg_pk_levels_ooo_kernel)
     int levels_threads = 64; // workgroup of the level walk (up to four waves per group)
     int lcap = 0, scap = 0;  // visit entries / stream words (entries + one header per particle) a tile may have

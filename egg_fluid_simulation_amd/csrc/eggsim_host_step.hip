@@ -204,7 +204,7 @@ void fill_packed_args(egg_handle *h, int which, const PackedClass &pc, const Env
     A.status = d_stat(s, s.parity);
     A.status_next = d_stat(s, s.parity ^ 1);
     A.tune = h->opt_tune;
-    A.lev_lds_cap = pc.lev_lds_cap;
+    A.lev_lds_cap = pc.lev_lds_now;
     A.simd_claims = h->simd_claims.p;
 }
 
@@ -214,6 +214,20 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
     if (s.pk_plan_dirty) {
         HIP_TRY(h, hipMemcpyAsync(s.pk_meta.p, s.pk_meta_host.data(), s.pk_meta_host.size() * sizeof(int32_t),
                                   hipMemcpyHostToDevice, st));
+    }
+    // The LDS level array of the out-of-order walk, per step: what the last step's longest pair stream asks for plus a
+    // quarter, never more than the re-tiling allowed.  (Sized at re-tiling only it stayed at the first steps' 77-80 KB per
+    // group for a whole run of config 3 -- two groups then fill a CU's 160 KB to the last 3 KB, and any workgroup of the
+    // yolk's kernels that holds LDS on the unit keeps the second group waiting.  A stream that outgrows the array fails
+    // the launch's check and the step is re-run, as before.)
+    for (PackedClass &pc : s.pk) {
+        if (!pc.levels_ooo) continue;
+        int now = pc.lev_lds_cap;
+        if (s.pk_seen_list) now = (int)std::min<size_t>((size_t)now, std::max<size_t>((size_t)(s.pk_seen_list + s.pk_seen_list / 4 + 256), s.pk_lev_lds_min));
+        now = std::min(pc.lev_lds_cap, (now + 7) & ~7);
+        pc.lev_lds_now = now;
+        pc.lds_levels_now = egg_pk_levels_ooo_lds_bytes(s.pk_lev_cap, pc.max_group_particles, pc.max_tiles_in_group, now);
+        pc.lds_pass_now = std::max(pc.lds_levels_now, pc.lds_exec + 64 * 16 + (size_t)EGG_PK_RING_BYTES);
     }
     std::vector<EggPackedArgs> args(s.pk.size());
     for (size_t k = 0; k < s.pk.size(); ++k) fill_packed_args(h, which, s.pk[k], env, S, C, args[k]);
@@ -272,7 +286,7 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
                         [stale](const PackedClass &pc) { return stale ? pc.threads_lists_stale : pc.threads_lists; },
                         [stale](const PackedClass &pc) { return stale ? pc.lds_lists_stale : pc.lds_lists; });
             launch_some(1, EGG_PK_KIND_LEVELS, [](const PackedClass &pc) { return pc.levels_ooo ? egg_pk_levels_ooo_kernel : egg_pk_levels_mr16_kernel; },
-                        groups_of, [](const PackedClass &pc) { return pc.levels_threads; }, [](const PackedClass &pc) { return pc.lds_levels; });
+                        groups_of, [](const PackedClass &pc) { return pc.levels_threads; }, [](const PackedClass &pc) { return pc.levels_ooo ? pc.lds_levels_now : pc.lds_levels; });
             {   // (the out-of-order walk sorts inside its own launch)
                 System::PkStamp *ps = nullptr;
                 for (size_t k = 0; k < s.pk.size(); ++k) {
@@ -291,7 +305,7 @@ int launch_packed(egg_handle *h, int which, const Env &env, int S, int C) {
                         [&](const PackedClass &pc) { return pc.lds_exec + (pc.n_groups <= simds ? 64 * 16 : 0); });
             // dense islands on a chip that is not full: levels, sort and executor of a group in one launch
             launch_some(2, EGG_PK_KIND_PASS, [](const PackedClass &) { return egg_pk_levexec_kernel; }, groups_of, [](const PackedClass &pc) { return pc.levels_threads; },
-                        [](const PackedClass &pc) { return pc.lds_pass; });
+                        [](const PackedClass &pc) { return pc.lds_pass_now; });
         }
     }
     launch_all(EGG_PK_KIND_END, [](const PackedClass &) { return egg_pk_end_kernel; }, tiles_of,
@@ -670,6 +684,7 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
             if (!s.pk.empty()) {
                 s.pk_seen_list = st.max_list;
                 s.pk_seen_levels = st.max_level;
+                s.pk_lev_lds_min = 0;  // (a committed step: the stream lengths it saw size the next one)
                 if (s.pk_group4_applies && egg_wants_group4(s) != s.pk_group4) s.tiling_dirty = true;  // (the grouping follows the shape of the dependency graph)
             }
 #ifdef EGG_PROFILE

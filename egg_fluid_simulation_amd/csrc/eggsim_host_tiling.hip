@@ -593,6 +593,10 @@ int retile(egg_handle *h, int which) {
                 if (pc.lds_pass > h->lds_limit) pc.fused_pass = 0;
             }
             pc.sort_cap = (int)sort_words;
+            pc.max_tiles_in_group = max_tiles_in_group;
+            pc.lev_lds_now = pc.lev_lds_cap;
+            pc.lds_levels_now = pc.lds_levels;
+            pc.lds_pass_now = pc.lds_pass;
             if (getenv("EGGSIM_DEBUG"))
                 fprintf(stderr, "eggsim: type %d packed class: %d tiles of <= %d particles in %d groups, grid cells %d (%s), lists: %d threads, %d staged partners, %zu B LDS; levels: %s, %d threads, %zu B LDS (level array %d entries); pass fused %d, %zu B LDS\n",
                         which, lc.n_tiles, lc.nmax, pc.n_groups, lc.ccap, lc.use_grid ? "dense grid" : "hash", pc.threads_lists, pc.stage_cap, pc.lds_lists,

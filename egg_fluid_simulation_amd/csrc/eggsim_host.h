@@ -167,9 +167,6 @@ struct LaunchClass {  // tiles of similar size share a launch (uniform LDS geome
 
 // A launch class in the packed pipeline: its tiles' particles occupy [p_begin, p_end) of the type's packed arrays,
 // consecutive tiles form GROUPS (one wave of egg_pk_levels / egg_pk_exec each).
-struct System;
-bool egg_wants_group4(const System &s);  // pairs per level and island below 5 (7 to go back): see retile
-
 struct PackedClass {
     int cls = 0;            // index into System::classes
     int n_tiles = 0, n_groups = 0;
@@ -270,8 +267,6 @@ struct System {  // one particle type
     size_t pk_sort_words = 0;                // sorted-list words over all packed groups
     int pk_lev_cap = 255;                    // levels the tables hold; grows when a group's DAG is deeper
     int pk_seen_levels = 0;                  // longest dependency chain (levels) of a pass of the last committed step
-    bool pk_group4 = false;                  // dense islands are grouped four to an executor (deep, narrow dependency graphs) instead of two
-    bool pk_group4_applies = false;          // ... and the scene is one where that choice exists (dense islands, more than two per CU)
     unsigned long long pk_seen_list = 0;     // longest pair stream any packed tile had in one pass of the last committed step
     size_t pk_lev_lds_min = 0;               // out-of-order walk: smallest LDS level array (entries per tile) after a fail_levlds
     bool pk_plan_dirty = true;

@@ -685,7 +685,6 @@ int do_step(egg_handle *h, double delta, int S, int C, int phase) {  // L:1722-1
                 s.pk_seen_list = st.max_list;
                 s.pk_seen_levels = st.max_level;
                 s.pk_lev_lds_min = 0;  // (a committed step: the stream lengths it saw size the next one)
-                if (s.pk_group4_applies && egg_wants_group4(s) != s.pk_group4) s.tiling_dirty = true;  // (the grouping follows the shape of the dependency graph)
             }
 #ifdef EGG_PROFILE
             if (getenv("EGGSIM_DEBUG") && !s.pk.empty())

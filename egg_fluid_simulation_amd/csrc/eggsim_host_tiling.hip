@@ -3,14 +3,6 @@
 
 namespace egghost {
 
-// Dense islands, four to an executor instead of two?  When a pass has fewer than 5 pairs per level and island (back to two
-// from 7: the scene drifts slowly, and a change of grouping is a re-tiling).
-bool egg_wants_group4(const System &s) {
-    if (s.pk_seen_levels <= 0) return false;
-    const double pairs_per_level = (double)s.pk_seen_list / (double)s.pk_seen_levels;
-    return pairs_per_level < (s.pk_group4 ? 7.0 : 5.0);
-}
-
 
 // ------------------------------------------------------------------ tiling
 
@@ -406,7 +398,6 @@ int retile(egg_handle *h, int which) {
     // ---- packed pipeline (eggsim_packed.hip): which classes take it, their packed ranges and groups
     s.pk.clear();
     s.pk_meta_host.clear();
-    s.pk_group4_applies = false;
     s.pk_n = s.pk_tiles = s.pk_groups = 0;
     s.pk_entries = 0;
     s.pk_sort_words = 0;
@@ -512,14 +503,9 @@ int retile(egg_handle *h, int which) {
                 const int64_t simds = 4 * (int64_t)std::max(1, h->prop.multiProcessorCount);
                 gp_auto = std::min<int64_t>(1280, std::max<int64_t>(320, (class_particles / simds + 159) / 160 * 160));
             }
-            else if (lc.n_tiles > 2 * std::max(1, h->prop.multiProcessorCount) && (s.pk_group4_applies = true, s.pk_group4 = egg_wants_group4(s))) {
-                // Dense islands whose dependency graph has become deep and narrow (config 3 after some hundred steps: 6,500
-                // pairs in 1,900 levels, 3-4 pairs per level and island): four islands to a group -- still one chunk per
-                // level, half as many executor waves and ONE group per CU, whose executor then has the CU's LDS to itself
-                // (542 instead of 586 cycles per level; with wider levels the chunks would split: +37 % chunks at 10 pairs
-                // per level and island, which is why this is not the rule).
-                gp_auto = 2560;
-            }
+            // (Four dense islands to an executor -- EGG_OPT_GROUP_PARTICLES = 2560, eight waves per fused group -- was 5 % faster
+            // for deep, narrow dependency graphs while two groups filled a CU's LDS; since the level array is sized per step it
+            // is 4 % slower there too -- 3.74 vs 3.59 ms per step after 600 steps of config 3 -- and is left to the option.)
             const int64_t gp_max = std::max<int64_t>(h->opt_group_particles > 0 ? h->opt_group_particles : gp_auto,
                                                      tiles[(size_t)lc.first_tile].particles);
             int max_tiles_in_group = 0;

@@ -93,8 +93,8 @@ def _check_budget_not_binding(st):
 @pytest.mark.parametrize("islands_per_executor", [2, 4])
 def test_config3_full_size_every_site_vs_oracle(egg, oracle_mod, islands_per_executor):
     """4,096 batches, four coincident per site, the automatic path: the scene bench.py times.  Four islands per executor
-    is the grouping the host switches to by itself once the dependency graphs are deep and narrow (hundreds of steps in);
-    forced here so that all 1,024 sites are compared on it as well."""
+    (an option, EGG_OPT_GROUP_PARTICLES: eight waves per fused group) is forced in the second case so that all 1,024 sites
+    are compared on that path as well."""
     # (four islands per executor: 40 steps, by which the pair streams have shrunk far enough for four islands' level arrays
     # to fit the LDS -- before that the host falls back to the in-order walk for such groups)
     n, overlap, steps = 4096, 4, (3 if islands_per_executor == 2 else 40)

@@ -272,9 +272,8 @@ def test_packed_pipeline_dense_and_sparse_islands_with_hand_made_chaos(egg, orac
 
 
 def test_fused_pass_with_four_dense_islands_to_an_executor(egg, oracle_mod):
-    """Deep, narrow dependency graphs are grouped four dense islands to an executor (retile: egg_wants_group4): the fused
-    pass then runs eight waves per group (two walk a tile, one executes, one helps).  Forced here with
-    EGG_OPT_GROUP_PARTICLES on six sites of four coincident batches -- groups of four and of two islands -- with the first
+    """Four dense islands to an executor (EGG_OPT_GROUP_PARTICLES = 2560; not the automatic choice): the fused pass then
+    runs eight waves per group (two walk a tile, one executes, one helps).  Six sites of four coincident batches -- groups of four and of two islands -- with the first
     steps' coincident particles (distance 0: the reference path inside the executor) and a moving target."""
     from egg_fluid_simulation_amd import _ffi
     h, o = _packed(egg, 2), oracle_mod.Oracle()

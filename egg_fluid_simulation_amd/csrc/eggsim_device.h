@@ -188,13 +188,16 @@ static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int us
     b += egg_align16(G * c * 4);                  // cell[gens]
     b += egg_align16(use_grid ? 0 : G * c * 4);   // hkeys[gens]
     b += egg_align16((n + 1) * 4);                // own_off
-    b += 2 * egg_align16(n * 4);                  // fill tmp
+    b += egg_align16(n * 4);                      // fill
     b += egg_align16(a * 4 * 4);                  // aclaim
     b += egg_align16((a + 1) * 4);                // aoff
     b += egg_align16(16 * 4);                     // scalars
     b += egg_align16(G * n * 2);                  // hitems[gens]
-    b += 2 * egg_align16(n * 2);                  // pslot aslot
-    b += egg_align16((size_t)stage_cap * n * 2);  // partners kept by the counting pass
+    b += egg_align16(n * 2);                      // aslot
+    {   // the partners kept by the counting pass; the grid builder's scratch (tmp, pslot) lives there before
+        const size_t stage = egg_align16((size_t)stage_cap * n * 2), tmp = egg_align16(n * 4) + egg_align16(n * 2);
+        b += stage > tmp ? stage : tmp;
+    }
     return b;
 }
 // egg_pk_levexec_kernel: the ring of ready-made pair records between its helper wave and its executor wave:

@@ -195,7 +195,7 @@ static inline size_t egg_pk_lists_lds_bytes(int nmax, int amax, int ccap, int us
     b += egg_align16(G * n * 2);                  // hitems[gens]
     b += egg_align16(n * 2);                      // aslot
     {   // the partners kept by the counting pass; the grid builder's scratch (tmp, pslot) lives there before
-        const size_t stage = egg_align16((size_t)stage_cap * n * 2), tmp = egg_align16(n * 4) + egg_align16(n * 2);
+        const size_t stage = egg_align16(((size_t)stage_cap + 1) * (n + 1) * 2), tmp = egg_align16(n * 4) + egg_align16(n * 2);  // ((n + 1) / 2 pairs of 2 stage_cap + 2 words)
         b += stage > tmp ? stage : tmp;
     }
     return b;

@@ -307,7 +307,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const 
         // which are first written when the grids are done: 3.8 KB less per dense tile, so that four of them leave a CU room
         // for the other stream's workgroups)
         {
-            const size_t stage_bytes = egg_align16((size_t)A.stage_cap * n * 2), tmp_bytes = egg_align16(n * 4) + egg_align16(n * 2);
+            const size_t stage_bytes = egg_align16(((size_t)A.stage_cap + 1) * (n + 1) * 2), tmp_bytes = egg_align16(n * 4) + egg_align16(n * 2);
             unsigned char *q = (unsigned char *)carve(p, stage_bytes > tmp_bytes ? stage_bytes : tmp_bytes);
             stage = (uint16_t *)q;
             tmp = (uint32_t *)q;
@@ -413,7 +413,9 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const 
         const int SC = A.stage_cap;
         for (int i = tid; i < n; i += nthreads) {
             const int m = n - 1 - i, pair = min(i, m);
-            uint16_t *slots = stage + (size_t)pair * 2 * SC;
+            // (a pair's slots are 2 SC + 2 words apart: with 2 SC = 32 words = 64 bytes the lanes of a wave -- consecutive
+            // pairs -- would all write into two of the 32 LDS banks)
+            uint16_t *slots = stage + (size_t)pair * (2 * SC + 2);
             const int cap = m == i ? SC : 2 * SC, at = i <= m ? 0 : 2 * SC - 1, dir = i <= m ? 1 : -1;
             auto keep = [&](int k, int j) {
                 if (k < cap) slots[at + dir * k] = (uint16_t)j;
@@ -463,7 +465,7 @@ __device__ __forceinline__ void egg_pk_lists_body(const EggPackedArgs &A, const 
                 dst[k] = (uint32_t)i | (slow ? 0x8000u : 0u) | ((uint32_t)j << 16);
             };
             const int m = n - 1 - i, pair = min(i, m);
-            const uint16_t *slots = stage + (size_t)pair * 2 * SC;
+            const uint16_t *slots = stage + (size_t)pair * (2 * SC + 2);
             const int at = i <= m ? 0 : 2 * SC - 1, dir = i <= m ? 1 : -1;
             const bool kept = m == i ? cnt <= SC : cnt + (int)t.fill[m] <= 2 * SC;  // (the two did not meet in the middle)
             if (kept && all_fast) {

@@ -271,6 +271,29 @@ def test_packed_pipeline_dense_and_sparse_islands_with_hand_made_chaos(egg, orac
     assert h.stats()["packed"][WHITE] >= 1 and _walk_used(h, walk)
 
 
+def test_fused_pass_stream_outgrows_its_lds_level_array(egg, oracle_mod):
+    """The out-of-order walk keeps a tile's levels in LDS, sized from the last step's longest pair stream + 25 %.  Two more
+    batches dropped onto a settled island of four more than double its stream: the launch reports that (fail_levlds),
+    the step is re-run with a larger array, and the result is the sequential one."""
+    h, o = _packed(egg, 2), oracle_mod.Oracle()
+    for _ in range(4):
+        assert h.add(400.0, 400.0, 50, 15) == o.add(400.0, 400.0, 50, 15)
+    for step in range(12):
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+    _same(h, o, "settled")
+    redo_before = h.stats()["redo_steps"]
+    for _ in range(2):
+        assert h.add(400.0, 400.0, 50, 15) == o.add(400.0, 400.0, 50, 15)
+    for step in range(3):
+        h.step(1 / 60, 2, 3)
+        o.step(1 / 60, 2, 3)
+        _same(h, o, step)
+    st = h.stats()
+    assert st["redo_steps"] > redo_before and st["max_tile_particles"][WHITE] == 6 * N_W, st
+    assert _walk_used(h, 2)
+
+
 def test_fused_pass_with_four_dense_islands_to_an_executor(egg, oracle_mod):
     """Four dense islands to an executor (EGG_OPT_GROUP_PARTICLES = 2560; not the automatic choice): the fused pass then
     runs eight waves per group (two walk a tile, one executes, one helps).  Six sites of four coincident batches -- groups of four and of two islands -- with the first

@@ -1615,6 +1615,7 @@ extern "C" __global__ void __launch_bounds__(512) egg_pk_levexec_kernel(EggPacke
 #ifdef EGG_PROFILE
     const unsigned long long R0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    __builtin_amdgcn_s_setprio(3);  // (the executor's instructions first wherever its SIMD is shared: -1 % of a late step)
     egg_pk_exec_consumer(A, g, ring);
     if ((threadIdx.x & 63) == 0 && claim_exec_s) atomicAnd(&A.simd_claims[claim_key_s], ~claim_exec_s);
 #ifdef EGG_PROFILE
